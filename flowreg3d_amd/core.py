@@ -1,0 +1,278 @@
+"""Host-side mirror of flowreg3d's flow-engine functions over the HIP C ABI.
+
+Same names, argument meaning, defaults, return shapes/dtypes and error behaviour as
+``flowreg3d.core.optical_flow_3d`` (get_displacement :319, imregister_wrapper :22, level_solver
+:262, get_motion_tensor_gc :92, warpingDepth :77, add_boundary :88) and
+``flowreg3d.util.resize_util_3D.imresize_fused_gauss_cubic3D`` (:114), so they can be passed as
+``get_displacement_func`` / ``imregister_func`` to the reference's executors or monkey-patched in.
+All arithmetic runs in hand-written gfx950 kernels (flowreg3d_amd/csrc); this file only reshapes,
+casts and validates.  No CPU fallback exists: without the built library / a GPU these raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["get_displacement", "imregister_wrapper", "level_solver", "get_motion_tensor_gc",
+           "imresize_fused_gauss_cubic3D", "tensor_factors", "warpingDepth", "add_boundary", "pyramid_schedule",
+           "expand_weight", "median_filter5"]
+
+
+def add_boundary(f):
+    """core/optical_flow_3d.py:88"""
+    return np.pad(f, 1, mode="edge")
+
+
+def warpingDepth(eta, levels, p, m, n):
+    """core/optical_flow_3d.py:77-85 (pure host logic, no GPU needed)."""
+    min_dim = min(p, m, n)
+    warpingdepth = 0
+    for _ in range(levels):
+        warpingdepth += 1
+        min_dim *= eta
+        if round(min_dim) < 10:
+            break
+    return warpingdepth
+
+
+def pyramid_schedule(p, m, n, eta, levels, min_level=0):
+    """Level sizes (coarse -> fine) and the effective min_level, computed by the engine's own
+    host code (fr3d_schedule; core/optical_flow_3d.py:389-408)."""
+    lib = _lib.load()
+    sizes = np.zeros((256, 3), np.int32)
+    eff = C.c_int(0)
+    cnt = lib.fr3d_schedule(int(p), int(m), int(n), float(eta), int(levels), int(min_level),
+                            sizes.ctypes.data_as(C.POINTER(C.c_int)), 256, C.byref(eff))
+    if cnt < 0:
+        raise ValueError(_lib.last_error())
+    return [tuple(int(v) for v in sizes[i]) for i in range(cnt)], int(eff.value)
+
+
+def expand_weight(weight, p, m, n, n_channels):
+    """Weight handling of get_displacement (core/optical_flow_3d.py:351-381) -> (p,m,n,C) float64,
+    or None for the default 1/C (the engine then builds the constant itself)."""
+    if weight is None:
+        return None
+    weight = np.asarray(weight).astype(np.float64)
+    if weight.ndim < 4:
+        if weight.ndim == 1:
+            if len(weight) < n_channels:
+                expanded = np.full(n_channels, 1.0 / n_channels, dtype=np.float64)
+                expanded[: len(weight)] = weight
+                weight = expanded
+            elif len(weight) > n_channels:
+                weight = weight[:n_channels]
+            weight = weight / weight.sum()
+            weight = np.ones((p, m, n, n_channels), dtype=np.float64) * weight.reshape(1, 1, 1, -1)
+        else:
+            weight = np.ones((p, m, n, n_channels), dtype=np.float64) * weight[..., np.newaxis]
+    if weight.shape != (p, m, n, n_channels):
+        raise ValueError(f"weight has shape {weight.shape}, expected {(p, m, n, n_channels)}")
+    return weight
+
+
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=20, min_level=0,
+                     levels=50, eta=0.8, a_smooth=0.5, a_data=0.45, const_assumption="gc",
+                     uvw=None, weight=None, solver_fp64=False):
+    """core/optical_flow_3d.py:319-542 -> (Z,Y,X,3) float64 with components [dx,dy,dz].
+
+    fixed/moving are used by the reference only through the fp32 resampler
+    (util/resize_util_3D.py:116), and uvw/weight likewise, so they cross the ABI as float32.
+    ``solver_fp64`` is an extension: fp64 update arithmetic in the SOR kernel (storage stays fp32).
+    """
+    fixed = np.asarray(fixed)
+    moving = np.asarray(moving)
+    if fixed.ndim == 3:
+        fixed = fixed[..., None]
+        moving = moving[..., None]
+    if fixed.ndim != 4 or moving.shape != fixed.shape:
+        raise ValueError("fixed and moving must have the same (Z,Y,X[,C]) shape")
+    if float(a_smooth) != 1.0:
+        raise NotImplementedError("a_smooth != 1.0 is not implemented on the device yet "
+                                  "(OFOptions default is 1.0; see DESIGN.md, out of scope)")
+    p, m, n, nc = fixed.shape
+    wt = expand_weight(weight, p, m, n, nc)
+    params = _lib.make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth, a_data, nc,
+                              solver_fp64)
+    f32, m32 = _f32c(fixed), _f32c(moving)
+    u32 = None
+    if uvw is not None:
+        u32 = _f32c(uvw)
+        if u32.shape != (p, m, n, 3):
+            raise ValueError(f"uvw has shape {u32.shape}, expected {(p, m, n, 3)}")
+    w32 = None if wt is None else _f32c(wt)
+    flow = np.empty((p, m, n, 3), np.float32)
+    lib = _lib.init()
+    _lib.check(lib.fr3d_get_displacement(C.byref(params), _lib.ptr(f32), _lib.ptr(m32), p, m, n, nc,
+                                         _lib.ptr(u32), _lib.ptr(w32), _lib.ptr(flow)))
+    return flow.astype(np.float64)
+
+
+def _order_of(interpolation_method):
+    m = str(interpolation_method).lower()
+    if m == "cubic":
+        return 3
+    if m == "linear":
+        return 1
+    raise ValueError("Unsupported interpolation method. Use 'linear' or 'cubic'.")
+
+
+def imregister_wrapper(f2_level, u, v, w, f1_level, interpolation_method="cubic"):
+    """core/optical_flow_3d.py:22-74 -> float32, channel axis dropped when C == 1."""
+    order = _order_of(interpolation_method)
+    f2 = np.asarray(f2_level)
+    f1 = np.asarray(f1_level)
+    if f2.ndim == 3:
+        f2 = f2[..., None]
+        f1 = f1[..., None]
+    Z, Y, X, nc = f2.shape
+    # volumes: float64 only when float32 would change values (the reference filters in float64)
+    if f2.dtype == np.float64 or f1.dtype == np.float64:
+        vdt, vt = _lib.F64, np.float64
+    else:
+        vdt, vt = _lib.F32, np.float32
+    vol = np.ascontiguousarray(f2, dtype=vt)
+    ref = np.ascontiguousarray(f1, dtype=vt)
+    comps = [np.broadcast_to(np.asarray(a), (Z, Y, X)) for a in (u, v, w)]
+    if any(c.dtype == np.float64 for c in comps):
+        fdt, ft = _lib.F64, np.float64
+    else:
+        fdt, ft = _lib.F32, np.float32
+    flow = np.empty((Z, Y, X, 3), ft)
+    for d in range(3):
+        flow[..., d] = comps[d]
+    out = np.empty((Z, Y, X, nc), np.float32)
+    lib = _lib.init()
+    _lib.check(lib.fr3d_warp(_lib.ptr(vol), vdt, _lib.ptr(flow), fdt, _lib.ptr(ref), Z, Y, X, nc, order,
+                             _lib.ptr(out)))
+    if nc == 1:
+        out = out[..., 0]
+    return out
+
+
+def imresize_fused_gauss_cubic3D(img, size, sigma_coeff=0.6, per_axis=False):
+    """util/resize_util_3D.py:114-156 for floating-point input (per_axis=False, sigma_coeff=0.6 --
+    the only form the flow path uses)."""
+    if per_axis or float(sigma_coeff) != 0.6:
+        raise NotImplementedError("only sigma_coeff=0.6, per_axis=False (the flow path's form)")
+    img = np.asarray(img)
+    if img.ndim not in (3, 4):
+        raise ValueError("img must be 3D or 4D with channels-last")
+    if np.issubdtype(img.dtype, np.integer):
+        raise NotImplementedError("integer images are not on the flow path")
+    od, oh, ow = (int(s) for s in size[:3])
+    x = img.astype(np.float32, copy=False)
+    x4 = x[..., None] if x.ndim == 3 else x
+    D, H, W, nc = x4.shape
+    out = np.empty((od, oh, ow, nc), np.float32)
+    lib = _lib.init()
+    for c in range(nc):
+        src = np.ascontiguousarray(x4[..., c])
+        dst = np.empty((od, oh, ow), np.float32)
+        _lib.check(lib.fr3d_resize3d(_lib.ptr(src), D, H, W, od, oh, ow, _lib.ptr(dst)))
+        out[..., c] = dst
+    if x.ndim == 3:
+        out = out[..., 0]
+    return out.astype(img.dtype, copy=False)
+
+
+def get_motion_tensor_gc(f1, f2, hz, hy, hx, return_factors=False):
+    """core/optical_flow_3d.py:92-152 -> 10 arrays (Z+2,Y+2,X+2) float64, outer ring zero, in the
+    order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34.  Values are the engine's fp32 storage.
+    ``return_factors`` additionally returns the (12,Z,Y,X) fp32 square-root factors the solver
+    evaluates psi_data from (include/flowreg3d_hip.h, fr3d_motion_tensor)."""
+    a, b = _f32c(f1), _f32c(f2)
+    if a.ndim != 3 or a.shape != b.shape:
+        raise ValueError("f1 and f2 must be 3-D arrays of equal shape")
+    Z, Y, X = a.shape
+    J = np.empty((10, Z, Y, X), np.float32)
+    A = np.empty((12, Z, Y, X), np.float32) if return_factors else None
+    lib = _lib.init()
+    _lib.check(lib.fr3d_motion_tensor(_lib.ptr(a), _lib.ptr(b), Z, Y, X, float(hz), float(hy), float(hx),
+                                      _lib.ptr(J), _lib.ptr(A)))
+    out = tuple(np.pad(J[k].astype(np.float64), 1) for k in range(10))
+    return (out, A) if return_factors else out
+
+
+def tensor_factors(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34):
+    """Rank-3 square-root factors A (12, ...) with J = sum_k a_k a_k^T (k = 0..2, a_k in R^4) of the
+    symmetric PSD 4x4 motion tensor given entry-wise (any leading shape), in float64.
+
+    The reference's tensor is a sum of three outer products (core/optical_flow_3d.py:134-143), so
+    the three leading eigenpairs reproduce it; psi_data's quadratic form d^T J d then becomes
+    sum_k (a_k . d)^2, which is how the device evaluates it."""
+    Js = [np.asarray(j, dtype=np.float64) for j in (J11, J22, J33, J44, J12, J13, J23, J14, J24, J34)]
+    shp = Js[0].shape
+    M = np.empty(shp + (4, 4), np.float64)
+    idx = {(0, 0): 0, (1, 1): 1, (2, 2): 2, (3, 3): 3, (0, 1): 4, (0, 2): 5, (1, 2): 6, (0, 3): 7, (1, 3): 8,
+           (2, 3): 9}
+    for (r, c), k in idx.items():
+        M[..., r, c] = Js[k]
+        M[..., c, r] = Js[k]
+    lam, V = np.linalg.eigh(M)          # ascending
+    lam = np.clip(lam[..., 1:], 0.0, None)  # three leading eigenvalues
+    V = V[..., :, 1:]
+    A = np.sqrt(lam)[..., None, :] * V  # (..., 4, 3): column k = a_k
+    A = np.moveaxis(A, (-1, -2), (0, 1)).reshape((12,) + shp)  # index 4k + column
+    return A
+
+
+def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v, w, alpha, iterations,
+                 update_lag, verbose, a_data, a_smooth, hx, hy, hz, solver_fp64=False):
+    """core/optical_flow_3d.py:262-316 -> (du, dv, dw), each (P,M,N) float64.
+
+    J*, weight: (P,M,N,C) with the zero outer ring; u,v,w: (P,M,N) edge-padded level flow.  Only the
+    interior is solved (as in the reference); the returned ghost ring is the edge pad of the
+    interior (the reference leaves the Neumann copy of the previous iterate there; it is never read
+    downstream, core/optical_flow_3d.py:517-535).  The tensor must be the rank-3 gradient-constancy
+    tensor get_motion_tensor_gc produces (see tensor_factors)."""
+    if float(a_smooth) != 1.0:
+        raise NotImplementedError("a_smooth != 1.0 is not implemented on the device yet")
+    Js = [np.asarray(j) for j in (J11, J22, J33, J44, J12, J13, J23, J14, J24, J34)]
+    if Js[0].ndim == 3:
+        Js = [j[..., None] for j in Js]
+    P, M, N, nc = Js[0].shape
+    wt = np.asarray(weight)
+    if wt.ndim == 3:
+        wt = wt[..., None]
+    inner = (slice(1, -1),) * 3
+    for name, a in (("u", u), ("v", v), ("w", w)):
+        a = np.asarray(a)
+        if a.shape != (P, M, N):
+            raise ValueError(f"{name} must have shape {(P, M, N)}")
+        if not np.array_equal(a, np.pad(a[inner], 1, mode="edge")):
+            raise NotImplementedError("u, v, w must be edge-padded (add_boundary) as in get_displacement")
+    Ji = [np.moveaxis(j[inner], -1, 0) for j in Js]  # each (C,Z,Y,X)
+    Jd = np.empty((9, nc, P - 2, M - 2, N - 2), np.float32)
+    for slot, k in enumerate((0, 1, 2, 4, 5, 6, 7, 8, 9)):
+        Jd[slot] = Ji[k]
+    Ad = _f32c(tensor_factors(*Ji))  # (12,C,Z,Y,X)
+    wd = _f32c(np.moveaxis(wt[inner], -1, 0))
+    uvw = np.stack([np.asarray(a)[inner] for a in (u, v, w)], 0).astype(np.float32)
+    out = np.empty((3, P - 2, M - 2, N - 2), np.float32)
+    al = (C.c_double * 3)(*[float(x) for x in alpha])
+    ad_np = np.broadcast_to(np.asarray(a_data, dtype=np.float64).reshape(-1), (nc,))
+    ad = (C.c_double * nc)(*[float(x) for x in ad_np])
+    lib = _lib.init()
+    _lib.check(lib.fr3d_level_solve(_lib.ptr(Jd), _lib.ptr(Ad), _lib.ptr(wd), _lib.ptr(uvw), P - 2, M - 2, N - 2,
+                                    nc, al, int(iterations), int(update_lag), ad, float(hx), float(hy),
+                                    float(hz), 1 if solver_fp64 else 0, _lib.ptr(out)))
+    return tuple(np.pad(out[d].astype(np.float64), 1, mode="edge") for d in range(3))
+
+
+def median_filter5(a):
+    """scipy.ndimage.median_filter(a, size=(5,5,5), mode='mirror') on the device (fp32)."""
+    x = _f32c(a)
+    if x.ndim != 3:
+        raise ValueError("3-D array expected")
+    out = np.empty_like(x)
+    lib = _lib.init()
+    _lib.check(lib.fr3d_median5(_lib.ptr(x), *x.shape, _lib.ptr(out)))
+    return out

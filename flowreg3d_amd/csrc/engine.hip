@@ -1,0 +1,976 @@
+// engine.hip -- host side of the gfx950 engine: device workspace, resampling tables, the
+// coarse-to-fine level loop of get_displacement (core/optical_flow_3d.py:319-542), the executor
+// per-volume body (parallelization/sequential_3d.py:148-175) and the C ABI of
+// include/flowreg3d_hip.h.  Everything between the entry copy-in and the exit copy-out stays in
+// HBM; the only host work per level is the (cached) table build and kernel launches.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "fr3d_internal.h"
+
+namespace fr3d {
+
+// ---------------------------------------------------------------------------------------------
+// schedule (core/optical_flow_3d.py:77-85, 389-408) -- Python round() is round-half-even
+// ---------------------------------------------------------------------------------------------
+static long py_round(double x) { return (long)std::nearbyint(x); }
+
+static int warping_depth(double eta, int levels, int p, int m, int n)
+{
+    double min_dim = (double)std::min(p, std::min(m, n));
+    int depth = 0;
+    for (int q = 0; q < levels; q++) {
+        depth += 1;
+        min_dim *= eta;
+        if (py_round(min_dim) < 10) break;
+    }
+    return depth;
+}
+
+struct Level {
+    int idx;  // pyramid index i (0 = full resolution)
+    int z, y, x;
+};
+
+static std::vector<Level> make_schedule(int p, int m, int n, double eta, int levels, int &min_level)
+{
+    int mlz = warping_depth(eta, levels, p, m, n);
+    int mly = warping_depth(eta, levels, m, n, p);
+    int mlx = warping_depth(eta, levels, n, p, m);
+    int ml = std::min(mlx, std::min(mly, mlz)) * 4;
+    mlz = std::min(mlz, ml); mly = std::min(mly, ml); mlx = std::min(mlx, ml);
+    int top = std::max(mlx, std::max(mly, mlz));
+    if (top <= min_level) min_level = top - 1;
+    if (min_level < 0) min_level = 0;
+    std::vector<Level> out;
+    for (int i = top; i >= min_level; i--) {
+        Level L;
+        L.idx = i;
+        L.z = (int)py_round((double)p * std::pow(eta, (double)std::min(i, mlz)));
+        L.y = (int)py_round((double)m * std::pow(eta, (double)std::min(i, mly)));
+        L.x = (int)py_round((double)n * std::pow(eta, (double)std::min(i, mlx)));
+        out.push_back(L);
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resampling tables (util/resize_util_3D.py:53-111), host side, fp32 exactly like the reference
+// run under NumPy promotion rules (fp64 cubic kernel rounded to fp32, fp32 products and sums).
+// ---------------------------------------------------------------------------------------------
+static double keys_cubic(double x)
+{
+    const double A = -0.75;
+    double ax = std::fabs(x);
+    if (ax < 1.0) return (A + 2.0) * std::pow(ax, 3.0) - (A + 3.0) * std::pow(ax, 2.0) + 1.0;
+    if (ax < 2.0) return A * std::pow(ax, 3.0) - 5.0 * A * std::pow(ax, 2.0) + 8.0 * A * ax - 4.0 * A;
+    return 0.0;
+}
+
+static int reflect_index(int j, int n)
+{
+    if (n <= 1) return 0;
+    while (j < 0 || j >= n) j = (j < 0) ? (-j - 1) : (2 * n - 1 - j);
+    return j;
+}
+
+static float pairwise_sum(const std::vector<float> &a)
+{
+    const int n = (int)a.size();
+    if (n < 8) {
+        float r = 0.0f;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    float r[8];
+    int i;
+    for (i = 0; i < 8; i++) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+struct HostTable {
+    int P;
+    std::vector<int> idx;
+    std::vector<float> wt;
+};
+
+static HostTable build_table(int in_len, int out_len, double sigma)
+{
+    const double scale = (double)out_len / (double)in_len;
+    int R = 0;
+    std::vector<float> g(1, 1.0f);
+    if (sigma > 0.0) {
+        R = (int)std::ceil(2.0 * sigma);
+        g.assign(2 * R + 1, 0.0f);
+        const float sig = (float)sigma;
+        for (int k = 0; k < 2 * R + 1; k++) {
+            float q = (float)(k - R) / sig;
+            g[k] = expf(-0.5f * (q * q));
+        }
+        float s = pairwise_sum(g);
+        for (auto &v : g) v = v / s;
+    }
+    HostTable t;
+    t.P = 2 * R + 4;
+    t.idx.resize((size_t)out_len * t.P);
+    t.wt.resize((size_t)out_len * t.P);
+    for (int i = 0; i < out_len; i++) {
+        double x = ((double)i + 0.5) / scale - 0.5;
+        int left = (int)std::floor(x - 2.0) - R;
+        float ssum = 0.0f;
+        for (int p = 0; p < t.P; p++) {
+            int j = left + p;
+            t.idx[(size_t)i * t.P + p] = reflect_index(j, in_len);
+            double d = x - (double)j;
+            float acc = 0.0f;
+            for (int u = -R; u <= R; u++) acc += g[u + R] * (float)keys_cubic(d - (double)u);
+            t.wt[(size_t)i * t.P + p] = acc;
+            ssum += acc;
+        }
+        float inv = 1.0f / ssum;
+        for (int p = 0; p < t.P; p++) t.wt[(size_t)i * t.P + p] *= inv;
+    }
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// engine state
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *ensure(size_t bytes)
+    {
+        if (bytes > cap) {
+            if (p) FR3D_HIP(hipFree(p));
+            p = nullptr; cap = 0;
+            size_t want = bytes + (bytes >> 4) + 256;
+            FR3D_HIP(hipMalloc(&p, want));
+            cap = want;
+        }
+        return p;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+};
+
+struct DevTable {
+    int P = 0;
+    int *idx = nullptr;
+    float *wt = nullptr;
+};
+
+struct ProfSpan {
+    int kid;
+    hipEvent_t a, b;
+};
+
+struct Engine {
+    bool inited = false;
+    int device = -1;
+    hipStream_t st = nullptr;
+    std::map<std::string, DevBuf> bufs;
+    std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
+    // profiling
+    bool prof = false;
+    std::vector<ProfSpan> spans;
+    std::vector<hipEvent_t> ev_pool;
+    fr3d_kernel_stat acc[FR3D_K_COUNT];
+
+    float *f32(const std::string &name, size_t n) { return (float *)bufs[name].ensure(n * sizeof(float)); }
+    double *f64(const std::string &name, size_t n) { return (double *)bufs[name].ensure(n * sizeof(double)); }
+
+    hipEvent_t get_event()
+    {
+        if (!ev_pool.empty()) {
+            hipEvent_t e = ev_pool.back();
+            ev_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        FR3D_HIP(hipEventCreate(&e));
+        return e;
+    }
+
+    const DevTable &table(int in_len, int out_len, double sigma)
+    {
+        long long bits;
+        std::memcpy(&bits, &sigma, sizeof(bits));
+        auto key = std::make_tuple(in_len, out_len, bits);
+        auto it = tables.find(key);
+        if (it != tables.end()) return it->second;
+        HostTable h = build_table(in_len, out_len, sigma);
+        DevTable d;
+        d.P = h.P;
+        FR3D_HIP(hipMalloc((void **)&d.idx, h.idx.size() * sizeof(int)));
+        FR3D_HIP(hipMalloc((void **)&d.wt, h.wt.size() * sizeof(float)));
+        FR3D_HIP(hipMemcpy(d.idx, h.idx.data(), h.idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        FR3D_HIP(hipMemcpy(d.wt, h.wt.data(), h.wt.size() * sizeof(float), hipMemcpyHostToDevice));
+        return tables.emplace(key, d).first->second;
+    }
+};
+
+static Engine g_eng;
+static std::recursive_mutex g_mu;
+static thread_local std::string g_err;
+
+struct Span {
+    Engine &e;
+    int kid;
+    hipEvent_t a = nullptr;
+    Span(Engine &eng, int k, double bytes, long long launches, long long units) : e(eng), kid(k)
+    {
+        if (!e.prof) return;
+        a = e.get_event();
+        FR3D_HIP(hipEventRecord(a, e.st));
+        e.acc[k].algo_bytes += bytes;
+        e.acc[k].launches += launches;
+        e.acc[k].units += units;
+    }
+    void add(double bytes, long long launches, long long units)
+    {
+        if (!e.prof) return;
+        e.acc[kid].algo_bytes += bytes;
+        e.acc[kid].launches += launches;
+        e.acc[kid].units += units;
+    }
+    ~Span()
+    {
+        if (!a) return;
+        hipEvent_t b = e.get_event();
+        (void)hipEventRecord(b, e.st);
+        e.spans.push_back({kid, a, b});
+    }
+};
+
+static void ensure_init()
+{
+    if (!g_eng.inited) throw Error("fr3d_init() has not been called (or failed)");
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage wrappers
+// ---------------------------------------------------------------------------------------------
+
+// imresize_fused_gauss_cubic3D for one channel: src (D,H,W) with channel stride cs/offset co
+// -> planar dst (od,oh,ow)
+static void resize3d(Engine &e, const float *src, int cs, int co, int D, int H, int W, int od, int oh,
+                     int ow, float *dst)
+{
+    double sz = (double)od / D, sy = (double)oh / H, sx = (double)ow / W;
+    double s = sx;
+    if (sy < s) s = sy;
+    if (sz < s) s = sz;
+    double sig = (s < 1.0) ? (0.6 / s) : 0.0;
+    const DevTable &tx = e.table(W, ow, sig);
+    const DevTable &ty = e.table(H, oh, sig);
+    const DevTable &tz = e.table(D, od, sig);
+    float *t1 = e.f32("rs_t1", (size_t)D * H * ow);
+    float *t2 = e.f32("rs_t2", (size_t)D * oh * ow);
+    double bytes = 4.0 * ((double)D * H * W + 2.0 * D * H * ow + 2.0 * D * oh * ow + (double)od * oh * ow);
+    Span sp(e, FR3D_K_RESIZE, bytes, 3, (long long)od * oh * ow);
+    launch_resize_pass(e.st, src, cs, co, D, H, W, 2, ow, tx.idx, tx.wt, tx.P, t1);
+    launch_resize_pass(e.st, t1, 1, 0, D, H, ow, 1, oh, ty.idx, ty.wt, ty.P, t2);
+    launch_resize_pass(e.st, t2, 1, 0, D, oh, ow, 0, od, tz.idx, tz.wt, tz.P, dst);
+}
+
+// cubic warp of one channel
+template <typename TV, typename TF>
+static void warp_cubic_chan(Engine &e, const TV *vol, int vcs, int vco, const TF *pu, const TF *pv,
+                            const TF *pw, int fs, double hx, double hy, double hz, const TV *ref,
+                            int Z, int Y, int X, float *out, int ocs, int oco)
+{
+    const int npad = 12;
+    const size_t np = (size_t)(Z + 2 * npad) * (Y + 2 * npad) * (X + 2 * npad);
+    double *coef = e.f64("warp_coef", np);
+    {
+        Span sp(e, FR3D_K_PREFILTER, 8.0 * np * 7.0, 4, (long long)np);
+        launch_pad_edge<TV>(e.st, vol, vcs, vco, Z, Y, X, npad, coef);
+        launch_prefilter3(e.st, coef, Z + 2 * npad, Y + 2 * npad, X + 2 * npad);
+    }
+    {
+        Span sp(e, FR3D_K_WARP, 24.0 * (double)Z * Y * X, 1, (long long)Z * Y * X);
+        launch_warp_cubic<TF, TV>(e.st, coef, npad, pu, pv, pw, fs, hx, hy, hz, ref, vcs, vco, Z, Y, X,
+                                  out, ocs, oco);
+    }
+}
+
+struct RefPyramid {
+    // per level, per channel planar arrays (owned by engine buffers)
+    std::vector<float *> f1;  // [level] -> C*nl floats
+    std::vector<float *> wl;  // [level] -> C*nl floats
+};
+
+// ---------------------------------------------------------------------------------------------
+// get_displacement on device pointers
+// ---------------------------------------------------------------------------------------------
+static void build_ref_pyramid(Engine &e, const std::vector<Level> &lv, const float *fixed,
+                              const float *weight, int Z, int Y, int X, int C, RefPyramid &rp,
+                              const std::string &tag)
+{
+    const size_t nfull = (size_t)Z * Y * X;
+    const float *wsrc = weight;
+    if (!weight) {
+        // weight=None -> ones/C (core/optical_flow_3d.py:351-352); resized like any other weight
+        float *wc = e.f32("w_const", nfull * C);
+        launch_fill(e.st, wc, (float)(1.0 / (double)C), (long long)nfull * C);
+        wsrc = wc;
+    }
+    rp.f1.clear();
+    rp.wl.clear();
+    for (size_t li = 0; li < lv.size(); li++) {
+        const Level &L = lv[li];
+        const size_t nl = (size_t)L.z * L.y * L.x;
+        float *f1 = e.f32(tag + "f1_" + std::to_string(li), nl * C);
+        float *wl = e.f32(tag + "wl_" + std::to_string(li), nl * C);
+        for (int c = 0; c < C; c++) {
+            resize3d(e, fixed, C, c, Z, Y, X, L.z, L.y, L.x, f1 + (size_t)c * nl);
+            resize3d(e, wsrc, C, c, Z, Y, X, L.z, L.y, L.x, wl + (size_t)c * nl);
+        }
+        rp.f1.push_back(f1);
+        rp.wl.push_back(wl);
+    }
+}
+
+static void get_displacement_core(Engine &e, const fr3d_params &p, const std::vector<Level> &lv,
+                                  int min_level, const RefPyramid &rp, const float *moving,
+                                  int Z, int Y, int X, int C, const float *uvw_init, float *flow_out)
+{
+    FR3D_CHECK(p.a_smooth == 1.0, "a_smooth != 1 is not implemented on the device (SURVEY 8f-3)");
+    const size_t nfull = (size_t)Z * Y * X;
+    float *uvw[3] = {nullptr, nullptr, nullptr};
+    float *uvw_prev[3];
+    int pz = 0, py = 0, px = 0;
+    int flip = 0;
+
+    for (size_t li = 0; li < lv.size(); li++) {
+        const Level &L = lv[li];
+        const int lz = L.z, ly = L.y, lx = L.x;
+        const size_t nl = (size_t)lz * ly * lx;
+        const double hz = (double)Z / lz, hy = (double)Y / ly, hx = (double)X / lx;
+        const float *f1l = rp.f1[li];
+        float *f2l = e.f32("f2l", nl * C);
+        for (int c = 0; c < C; c++) resize3d(e, moving, C, c, Z, Y, X, lz, ly, lx, f2l + (size_t)c * nl);
+
+        // level flow (interior; ghosts are the edge pad of :88-89, implied)
+        for (int d = 0; d < 3; d++) uvw_prev[d] = uvw[d];
+        const std::string sfx = flip ? "_a" : "_b";
+        flip ^= 1;
+        for (int d = 0; d < 3; d++) uvw[d] = e.f32(std::string("uvw") + char('0' + d) + sfx, nl);
+        const float *warped = f2l;
+        if (li == 0) {
+            for (int d = 0; d < 3; d++) {
+                if (uvw_init) resize3d(e, uvw_init, 3, d, Z, Y, X, lz, ly, lx, uvw[d]);
+                else launch_fill(e.st, uvw[d], 0.0f, (long long)nl);
+            }
+        } else {
+            for (int d = 0; d < 3; d++) resize3d(e, uvw_prev[d], 1, 0, pz, py, px, lz, ly, lx, uvw[d]);
+            float *wbuf = e.f32("warped", nl * C);
+            for (int c = 0; c < C; c++)
+                warp_cubic_chan<float, float>(e, f2l + (size_t)c * nl, 1, 0, uvw[0], uvw[1], uvw[2], 1,
+                                              hx, hy, hz, f1l + (size_t)c * nl, lz, ly, lx,
+                                              wbuf + (size_t)c * nl, 1, 0);
+            warped = wbuf;
+        }
+
+        // solver operands in the skewed layout
+        const Skew sk = make_skew(lz, ly, lx);
+        const size_t ns = (size_t)sk.total;
+        float *Jbuf = e.f32("J_sk", ns * 9 * C);
+        float *Abuf = e.f32("A_sk", ns * 12 * C);
+        float *wsk = e.f32("w_sk", ns * C);
+        float *wpsi = e.f32("wpsi_sk", ns * C);
+        float *Lbuf = e.f32("L_sk", ns * 3);
+        float *dbuf = e.f32("d_sk", ns * 3);
+        SorArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.sk = sk;
+        a.C = C;
+        {
+            Span sp(e, FR3D_K_TENSOR, 4.0 * (2 + 21) * nl * C, C, (long long)nl * C);
+            for (int c = 0; c < C; c++) {
+                // reference order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 -> solver slots (J44 is
+                // not stored: psi comes from the factors)
+                float *base = Jbuf + (size_t)c * 9 * ns;
+                float *abase = Abuf + (size_t)c * 12 * ns;
+                float *Jo[10] = {base + 0 * ns, base + 1 * ns, base + 2 * ns, nullptr, base + 3 * ns,
+                                 base + 4 * ns, base + 5 * ns, base + 6 * ns, base + 7 * ns, base + 8 * ns};
+                launch_motion_tensor(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
+                                     hx, Jo, abase, (long long)ns, &sk);
+                for (int q = 0; q < 9; q++) a.J[q * FR3D_MAX_CHANNELS + c] = base + (size_t)q * ns;
+                for (int q = 0; q < 12; q++) a.A[q * FR3D_MAX_CHANNELS + c] = abase + (size_t)q * ns;
+                a.weight[c] = wsk + (size_t)c * ns;
+                a.wpsi[c] = wpsi + (size_t)c * ns;
+                a.a_data[c] = p.a_data[c];
+            }
+        }
+        {
+            Span sp(e, FR3D_K_OTHER, 0, 0, 0);
+            for (int c = 0; c < C; c++) launch_skew_copy(e.st, rp.wl[li] + (size_t)c * nl, sk, wsk + (size_t)c * ns);
+            // alpha schedule (:485-490) and alpha/h^2 (level_solver_3d.py:473-475)
+            const double sc = (L.idx == min_level) ? 1.0 : std::pow(p.eta, -0.5 * (double)L.idx);
+            a.ax = (sc * p.alpha[0]) / (hx * hx);
+            a.ay = (sc * p.alpha[1]) / (hy * hy);
+            a.az = (sc * p.alpha[2]) / (hz * hz);
+            for (int d = 0; d < 3; d++) {
+                a.L[d] = Lbuf + (size_t)d * ns;
+                a.d[d] = dbuf + (size_t)d * ns;
+            }
+            launch_laplace(e.st, uvw[0], uvw[1], uvw[2], sk, a.ax, a.ay, a.az, Lbuf, Lbuf + ns, Lbuf + 2 * ns);
+            FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * sizeof(float), e.st));
+        }
+        a.iterations = p.iterations;
+        a.update_lag = p.update_lag;
+        {
+            Span sp(e, FR3D_K_SOR, 0, 0, 0);
+            long long n = launch_sor(e.st, a, p.solver_fp64 != 0);
+            sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations, n, (long long)nl * p.iterations);
+        }
+        // increments back to the natural layout, 5^3 median (:517-526), accumulate (:527-529)
+        float *dn = e.f32("d_nat", nl * 3);
+        float *dm = e.f32("d_med", nl * 3);
+        {
+            Span sp(e, FR3D_K_OTHER, 0, 0, 0);
+            for (int d = 0; d < 3; d++) launch_unskew_copy(e.st, dbuf + (size_t)d * ns, sk, dn + (size_t)d * nl);
+        }
+        const bool med = std::min(lz, std::min(ly, lx)) > 5;
+        if (med) {
+            Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);
+            for (int d = 0; d < 3; d++) launch_median5(e.st, dn + (size_t)d * nl, lz, ly, lx, dm + (size_t)d * nl);
+        }
+        {
+            Span sp(e, FR3D_K_OTHER, 0, 0, 0);
+            for (int d = 0; d < 3; d++) launch_axpy(e.st, uvw[d], (med ? dm : dn) + (size_t)d * nl, (long long)nl);
+        }
+        pz = lz; py = ly; px = lx;
+    }
+
+    // :530-541
+    {
+        const size_t nl = (size_t)pz * py * px;
+        if (min_level > 0) {
+            float *full = e.f32("flow_full", nfull * 3);
+            for (int d = 0; d < 3; d++) resize3d(e, uvw[d], 1, 0, pz, py, px, Z, Y, X, full + (size_t)d * nfull);
+            launch_pack(e.st, full, 3, (long long)nfull, flow_out);
+        } else {
+            FR3D_CHECK(nl == nfull, "internal: finest level is not full resolution");
+            float *tmp = e.f32("flow_full", nfull * 3);
+            for (int d = 0; d < 3; d++)
+                FR3D_HIP(hipMemcpyAsync(tmp + (size_t)d * nfull, uvw[d], nfull * sizeof(float),
+                                        hipMemcpyDeviceToDevice, e.st));
+            launch_pack(e.st, tmp, 3, (long long)nfull, flow_out);
+        }
+    }
+}
+
+static void check_params(const fr3d_params *p, int Z, int Y, int X, int C)
+{
+    FR3D_CHECK(p != nullptr, "params is NULL");
+    FR3D_CHECK(Z >= 1 && Y >= 1 && X >= 1, "volume dimensions must be >= 1");
+    FR3D_CHECK(C >= 1 && C <= 4, "1..4 channels are supported");
+    FR3D_CHECK(p->iterations >= 0 && p->update_lag >= 1, "iterations >= 0 and update_lag >= 1 required");
+    FR3D_CHECK(p->eta > 0.0 && p->eta < 1.0, "eta must be in (0,1)");
+    FR3D_CHECK(p->levels >= 1, "levels must be >= 1");
+}
+
+static void get_displacement_dev(const fr3d_params *p, const float *fixed, const float *moving, int Z,
+                                 int Y, int X, int C, const float *uvw_init, const float *weight,
+                                 float *flow_out)
+{
+    ensure_init();
+    check_params(p, Z, Y, X, C);
+    FR3D_CHECK(fixed && moving && flow_out, "NULL volume pointer");
+    Engine &e = g_eng;
+    int min_level = p->min_level;
+    std::vector<Level> lv = make_schedule(Z, Y, X, p->eta, p->levels, min_level);
+    RefPyramid rp;
+    build_ref_pyramid(e, lv, fixed, weight, Z, Y, X, C, rp, "gd_");
+    get_displacement_core(e, *p, lv, min_level, rp, moving, Z, Y, X, C, uvw_init, flow_out);
+    FR3D_HIP(hipStreamSynchronize(e.st));
+}
+
+template <typename TV, typename TF>
+static void warp_dev_t(const TV *vol, const TF *flow, const TV *ref, int Z, int Y, int X, int C, int order,
+                       float *out)
+{
+    Engine &e = g_eng;
+    for (int c = 0; c < C; c++) {
+        if (order == 3) {
+            warp_cubic_chan<TV, TF>(e, vol, C, c, flow + 0, flow + 1, flow + 2, 3, 1.0, 1.0, 1.0, ref, Z, Y,
+                                    X, out, C, c);
+        } else {
+            Span sp(e, FR3D_K_WARP, 24.0 * (double)Z * Y * X, 1, (long long)Z * Y * X);
+            launch_warp_linear<TV, TF>(e.st, vol, C, c, flow + 0, flow + 1, flow + 2, 3, ref, Z, Y, X, out,
+                                       C, c);
+        }
+    }
+}
+
+static void warp_dev(const void *vol, int vdt, const void *flow, int fdt, const void *ref, int Z, int Y,
+                     int X, int C, int order, float *out)
+{
+    ensure_init();
+    FR3D_CHECK(order == 1 || order == 3, "Unsupported interpolation method. Use 'linear' or 'cubic'.");
+    FR3D_CHECK(Z >= 1 && Y >= 1 && X >= 1 && C >= 1, "bad warp shape");
+    FR3D_CHECK(vol && flow && ref && out, "NULL pointer");
+    if (vdt == FR3D_F32 && fdt == FR3D_F32)
+        warp_dev_t<float, float>((const float *)vol, (const float *)flow, (const float *)ref, Z, Y, X, C, order, out);
+    else if (vdt == FR3D_F32 && fdt == FR3D_F64)
+        warp_dev_t<float, double>((const float *)vol, (const double *)flow, (const float *)ref, Z, Y, X, C, order, out);
+    else if (vdt == FR3D_F64 && fdt == FR3D_F32)
+        warp_dev_t<double, float>((const double *)vol, (const float *)flow, (const double *)ref, Z, Y, X, C, order, out);
+    else if (vdt == FR3D_F64 && fdt == FR3D_F64)
+        warp_dev_t<double, double>((const double *)vol, (const double *)flow, (const double *)ref, Z, Y, X, C, order, out);
+    else
+        throw Error("unknown dtype code");
+    FR3D_HIP(hipStreamSynchronize(g_eng.st));
+}
+
+static void process_batch_dev(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
+                              const float *ref_proc, const float *ref_raw, const float *w_init,
+                              const float *weight, int T, int Z, int Y, int X, int C, int order,
+                              float *flows_out, float *registered_out, fr3d_progress_fn progress, void *user)
+{
+    ensure_init();
+    check_params(p, Z, Y, X, C);
+    FR3D_CHECK(order == 1 || order == 3, "Unsupported interpolation method. Use 'linear' or 'cubic'.");
+    FR3D_CHECK(T >= 0, "T must be >= 0");
+    Engine &e = g_eng;
+    int min_level = p->min_level;
+    std::vector<Level> lv = make_schedule(Z, Y, X, p->eta, p->levels, min_level);
+    RefPyramid rp;
+    // the fixed-reference pyramid and the weight pyramid are time-invariant: build once
+    build_ref_pyramid(e, lv, ref_proc, weight, Z, Y, X, C, rp, "pb_");
+    const size_t nv = (size_t)Z * Y * X;
+    for (int t = 0; t < T; t++) {
+        float *flow = flows_out + (size_t)t * nv * 3;
+        get_displacement_core(e, *p, lv, min_level, rp, batch_proc + (size_t)t * nv * C, Z, Y, X, C, w_init,
+                              flow);
+        warp_dev_t<float, float>(batch_raw + (size_t)t * nv * C, flow, ref_raw, Z, Y, X, C, order,
+                                 registered_out + (size_t)t * nv * C);
+        if (progress) {
+            FR3D_HIP(hipStreamSynchronize(e.st));
+            progress(1, user);
+        }
+    }
+    FR3D_HIP(hipStreamSynchronize(e.st));
+}
+
+// host staging helper
+struct Staged {
+    std::vector<void *> ptrs;
+    void *up(const void *host, size_t bytes)
+    {
+        if (!host) return nullptr;
+        void *d = nullptr;
+        FR3D_HIP(hipMalloc(&d, bytes ? bytes : 1));
+        ptrs.push_back(d);
+        FR3D_HIP(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+        return d;
+    }
+    void *alloc(size_t bytes)
+    {
+        void *d = nullptr;
+        FR3D_HIP(hipMalloc(&d, bytes ? bytes : 1));
+        ptrs.push_back(d);
+        return d;
+    }
+    ~Staged()
+    {
+        for (void *q : ptrs) (void)hipFree(q);
+    }
+};
+
+}  // namespace fr3d
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace fr3d;
+
+#define FR3D_TRY try { std::lock_guard<std::recursive_mutex> lk__(g_mu);
+#define FR3D_CATCH                                                                              \
+    }                                                                                           \
+    catch (const std::exception &ex) { g_err = ex.what(); return 1; }                           \
+    catch (...) { g_err = "unknown error"; return 1; }                                          \
+    return 0;
+
+extern "C" {
+
+const char *fr3d_last_error(void) { return g_err.c_str(); }
+const char *fr3d_version(void) { return "flowreg3d_amd 0.1 (gfx950)"; }
+
+int fr3d_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fr3d_init(int device)
+{
+    FR3D_TRY
+    if (g_eng.inited && g_eng.device == device) return 0;
+    if (g_eng.inited) throw Error("engine already initialised on another device; call fr3d_shutdown first");
+    int n = 0;
+    FR3D_HIP(hipGetDeviceCount(&n));
+    FR3D_CHECK(n > 0, "no HIP device visible");
+    FR3D_CHECK(device >= 0 && device < n, "device index out of range");
+    FR3D_HIP(hipSetDevice(device));
+    FR3D_HIP(hipStreamCreateWithFlags(&g_eng.st, hipStreamNonBlocking));
+    g_eng.device = device;
+    std::memset(g_eng.acc, 0, sizeof(g_eng.acc));
+    g_eng.inited = true;
+    FR3D_CATCH
+}
+
+void fr3d_shutdown(void)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!g_eng.inited) return;
+    (void)hipStreamSynchronize(g_eng.st);
+    for (auto &kv : g_eng.bufs) kv.second.release();
+    g_eng.bufs.clear();
+    for (auto &kv : g_eng.tables) {
+        (void)hipFree(kv.second.idx);
+        (void)hipFree(kv.second.wt);
+    }
+    g_eng.tables.clear();
+    for (auto &s : g_eng.spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    g_eng.spans.clear();
+    for (auto ev : g_eng.ev_pool) (void)hipEventDestroy(ev);
+    g_eng.ev_pool.clear();
+    (void)hipStreamDestroy(g_eng.st);
+    g_eng.st = nullptr;
+    g_eng.inited = false;
+    g_eng.device = -1;
+}
+
+int fr3d_get_displacement_dev(const fr3d_params *p, const float *fixed, const float *moving, int Z, int Y,
+                              int X, int C, const float *uvw_init, const float *weight, float *flow_out)
+{
+    FR3D_TRY
+    get_displacement_dev(p, fixed, moving, Z, Y, X, C, uvw_init, weight, flow_out);
+    FR3D_CATCH
+}
+
+int fr3d_get_displacement(const fr3d_params *p, const float *fixed, const float *moving, int Z, int Y, int X,
+                          int C, const float *uvw_init, const float *weight, float *flow_out)
+{
+    FR3D_TRY
+    ensure_init();
+    check_params(p, Z, Y, X, C);
+    FR3D_CHECK(fixed && moving && flow_out, "NULL volume pointer");
+    const size_t nv = (size_t)Z * Y * X;
+    Staged s;
+    const float *df = (const float *)s.up(fixed, nv * C * 4);
+    const float *dm = (const float *)s.up(moving, nv * C * 4);
+    const float *du = (const float *)s.up(uvw_init, nv * 3 * 4);
+    const float *dw = (const float *)s.up(weight, nv * C * 4);
+    float *dout = (float *)s.alloc(nv * 3 * 4);
+    get_displacement_dev(p, df, dm, Z, Y, X, C, du, dw, dout);
+    FR3D_HIP(hipMemcpy(flow_out, dout, nv * 3 * 4, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_warp_dev(const void *vol, int vol_dtype, const void *flow, int flow_dtype, const void *ref, int Z,
+                  int Y, int X, int C, int order, float *out)
+{
+    FR3D_TRY
+    warp_dev(vol, vol_dtype, flow, flow_dtype, ref, Z, Y, X, C, order, out);
+    FR3D_CATCH
+}
+
+int fr3d_warp(const void *vol, int vol_dtype, const void *flow, int flow_dtype, const void *ref, int Z, int Y,
+              int X, int C, int order, float *out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(order == 1 || order == 3, "Unsupported interpolation method. Use 'linear' or 'cubic'.");
+    FR3D_CHECK(Z >= 1 && Y >= 1 && X >= 1 && C >= 1, "bad warp shape");
+    FR3D_CHECK(vol && flow && ref && out, "NULL pointer");
+    FR3D_CHECK((vol_dtype == FR3D_F32 || vol_dtype == FR3D_F64) && (flow_dtype == FR3D_F32 || flow_dtype == FR3D_F64),
+               "unknown dtype code");
+    const size_t nv = (size_t)Z * Y * X;
+    const size_t vb = vol_dtype == FR3D_F64 ? 8 : 4, fb = flow_dtype == FR3D_F64 ? 8 : 4;
+    Staged s;
+    const void *dv = s.up(vol, nv * C * vb);
+    const void *dr = s.up(ref, nv * C * vb);
+    const void *dfl = s.up(flow, nv * 3 * fb);
+    float *dout = (float *)s.alloc(nv * C * 4);
+    warp_dev(dv, vol_dtype, dfl, flow_dtype, dr, Z, Y, X, C, order, dout);
+    FR3D_HIP(hipMemcpy(out, dout, nv * C * 4, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_process_batch_dev(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
+                           const float *ref_proc, const float *ref_raw, const float *w_init,
+                           const float *weight, int T, int Z, int Y, int X, int C, int order, float *flows_out,
+                           float *registered_out, fr3d_progress_fn progress, void *user)
+{
+    FR3D_TRY
+    FR3D_CHECK(batch_proc && batch_raw && ref_proc && ref_raw && flows_out && registered_out, "NULL pointer");
+    process_batch_dev(p, batch_proc, batch_raw, ref_proc, ref_raw, w_init, weight, T, Z, Y, X, C, order,
+                      flows_out, registered_out, progress, user);
+    FR3D_CATCH
+}
+
+int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
+                       const float *ref_proc, const float *ref_raw, const float *w_init, const float *weight,
+                       int T, int Z, int Y, int X, int C, int order, float *flows_out, float *registered_out,
+                       fr3d_progress_fn progress, void *user)
+{
+    FR3D_TRY
+    ensure_init();
+    check_params(p, Z, Y, X, C);
+    FR3D_CHECK(batch_proc && batch_raw && ref_proc && ref_raw && flows_out && registered_out, "NULL pointer");
+    FR3D_CHECK(T >= 0, "T must be >= 0");
+    const size_t nv = (size_t)Z * Y * X;
+    Staged s;
+    const float *dbp = (const float *)s.up(batch_proc, nv * C * 4 * (size_t)T);
+    const float *dbr = (const float *)s.up(batch_raw, nv * C * 4 * (size_t)T);
+    const float *drp = (const float *)s.up(ref_proc, nv * C * 4);
+    const float *drr = (const float *)s.up(ref_raw, nv * C * 4);
+    const float *dwi = (const float *)s.up(w_init, nv * 3 * 4);
+    const float *dwt = (const float *)s.up(weight, nv * C * 4);
+    float *dfl = (float *)s.alloc(nv * 3 * 4 * (size_t)T);
+    float *dre = (float *)s.alloc(nv * C * 4 * (size_t)T);
+    process_batch_dev(p, dbp, dbr, drp, drr, dwi, dwt, T, Z, Y, X, C, order, dfl, dre, progress, user);
+    FR3D_HIP(hipMemcpy(flows_out, dfl, nv * 3 * 4 * (size_t)T, hipMemcpyDeviceToHost));
+    FR3D_HIP(hipMemcpy(registered_out, dre, nv * C * 4 * (size_t)T, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+// ---- kernel-level entry points ------------------------------------------------------------------
+
+int fr3d_resize3d(const float *src, int D, int H, int W, int od, int oh, int ow, float *dst)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(src && dst && D > 0 && H > 0 && W > 0 && od > 0 && oh > 0 && ow > 0, "bad resize arguments");
+    Staged s;
+    const float *ds = (const float *)s.up(src, (size_t)D * H * W * 4);
+    float *dd = (float *)s.alloc((size_t)od * oh * ow * 4);
+    resize3d(g_eng, ds, 1, 0, D, H, W, od, oh, ow, dd);
+    FR3D_HIP(hipStreamSynchronize(g_eng.st));
+    FR3D_HIP(hipMemcpy(dst, dd, (size_t)od * oh * ow * 4, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_motion_tensor(const float *f1, const float *f2, int Z, int Y, int X, double hz, double hy, double hx,
+                       float *J, float *A)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(f1 && f2 && J && Z > 0 && Y > 0 && X > 0, "bad tensor arguments");
+    const size_t n = (size_t)Z * Y * X;
+    Staged s;
+    const float *d1 = (const float *)s.up(f1, n * 4);
+    const float *d2 = (const float *)s.up(f2, n * 4);
+    float *dj = (float *)s.alloc(n * 10 * 4);
+    float *da = A ? (float *)s.alloc(n * 12 * 4) : nullptr;
+    float *Jo[10];
+    for (int a = 0; a < 10; a++) Jo[a] = dj + (size_t)a * n;
+    launch_motion_tensor(g_eng.st, d1, d2, Z, Y, X, hz, hy, hx, Jo, da, (long long)n, nullptr);
+    FR3D_HIP(hipStreamSynchronize(g_eng.st));
+    FR3D_HIP(hipMemcpy(J, dj, n * 10 * 4, hipMemcpyDeviceToHost));
+    if (A) FR3D_HIP(hipMemcpy(A, da, n * 12 * 4, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_level_solve(const float *J, const float *A, const float *weight, const float *uvw, int Z, int Y, int X,
+                     int C, const double *alpha3, int iterations, int update_lag, const double *a_data,
+                     double hx, double hy, double hz, int solver_fp64, float *duvw_out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(J && A && weight && uvw && alpha3 && a_data && duvw_out, "NULL pointer");
+    FR3D_CHECK(Z > 0 && Y > 0 && X > 0 && C >= 1 && C <= 4, "bad solver shape");
+    FR3D_CHECK(iterations >= 0 && update_lag >= 1, "iterations >= 0 and update_lag >= 1 required");
+    Engine &e = g_eng;
+    const size_t n = (size_t)Z * Y * X;
+    const Skew sk = make_skew(Z, Y, X);
+    const size_t ns = (size_t)sk.total;
+    Staged s;
+    const float *dJ = (const float *)s.up(J, n * 9 * C * 4);
+    const float *dA = (const float *)s.up(A, n * 12 * C * 4);
+    const float *dW = (const float *)s.up(weight, n * C * 4);
+    const float *dU = (const float *)s.up(uvw, n * 3 * 4);
+    float *Jsk = (float *)s.alloc(ns * 9 * C * 4);
+    float *Ask = (float *)s.alloc(ns * 12 * C * 4);
+    float *wsk = (float *)s.alloc(ns * C * 4);
+    float *wpsi = (float *)s.alloc(ns * C * 4);
+    float *Lb = (float *)s.alloc(ns * 3 * 4);
+    float *db = (float *)s.alloc(ns * 3 * 4);
+    float *dn = (float *)s.alloc(n * 3 * 4);
+    SorArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.sk = sk;
+    a.C = C;
+    for (int q = 0; q < 9; q++)
+        for (int c = 0; c < C; c++) {
+            float *dst = Jsk + ((size_t)q * C + c) * ns;
+            launch_skew_copy(e.st, dJ + ((size_t)q * C + c) * n, sk, dst);
+            a.J[q * FR3D_MAX_CHANNELS + c] = dst;
+        }
+    for (int q = 0; q < 12; q++)
+        for (int c = 0; c < C; c++) {
+            float *dst = Ask + ((size_t)q * C + c) * ns;
+            launch_skew_copy(e.st, dA + ((size_t)q * C + c) * n, sk, dst);
+            a.A[q * FR3D_MAX_CHANNELS + c] = dst;
+        }
+    for (int c = 0; c < C; c++) {
+        launch_skew_copy(e.st, dW + (size_t)c * n, sk, wsk + (size_t)c * ns);
+        a.weight[c] = wsk + (size_t)c * ns;
+        a.wpsi[c] = wpsi + (size_t)c * ns;
+        a.a_data[c] = a_data[c];
+    }
+    a.ax = alpha3[0] / (hx * hx);
+    a.ay = alpha3[1] / (hy * hy);
+    a.az = alpha3[2] / (hz * hz);
+    for (int d = 0; d < 3; d++) {
+        a.L[d] = Lb + (size_t)d * ns;
+        a.d[d] = db + (size_t)d * ns;
+    }
+    launch_laplace(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lb, Lb + ns, Lb + 2 * ns);
+    FR3D_HIP(hipMemsetAsync(db, 0, ns * 3 * 4, e.st));
+    a.iterations = iterations;
+    a.update_lag = update_lag;
+    launch_sor(e.st, a, solver_fp64 != 0);
+    for (int d = 0; d < 3; d++) launch_unskew_copy(e.st, db + (size_t)d * ns, sk, dn + (size_t)d * n);
+    FR3D_HIP(hipStreamSynchronize(e.st));
+    FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 4, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_median5(const float *in, int Z, int Y, int X, float *out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(in && out && Z > 0 && Y > 0 && X > 0, "bad median arguments");
+    const size_t n = (size_t)Z * Y * X;
+    Staged s;
+    const float *di = (const float *)s.up(in, n * 4);
+    float *dout = (float *)s.alloc(n * 4);
+    launch_median5(g_eng.st, di, Z, Y, X, dout);
+    FR3D_HIP(hipStreamSynchronize(g_eng.st));
+    FR3D_HIP(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_schedule(int Z, int Y, int X, double eta, int levels, int min_level, int *sizes, int max_out,
+                  int *min_level_eff)
+{
+    try {
+        if (Z < 1 || Y < 1 || X < 1 || !(eta > 0.0 && eta < 1.0) || levels < 1) {
+            g_err = "bad schedule arguments";
+            return -1;
+        }
+        std::vector<Level> lv = make_schedule(Z, Y, X, eta, levels, min_level);
+        for (size_t i = 0; i < lv.size() && (int)i < max_out && sizes; i++) {
+            sizes[3 * i + 0] = lv[i].z;
+            sizes[3 * i + 1] = lv[i].y;
+            sizes[3 * i + 2] = lv[i].x;
+        }
+        if (min_level_eff) *min_level_eff = min_level;
+        return (int)lv.size();
+    } catch (...) {
+        g_err = "schedule failed";
+        return -1;
+    }
+}
+
+// ---- memory helpers -----------------------------------------------------------------------------
+
+void *fr3d_dev_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        g_err = "hipMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+void fr3d_dev_free(void *p)
+{
+    if (p) (void)hipFree(p);
+}
+int fr3d_h2d(void *dst, const void *src, size_t bytes)
+{
+    FR3D_TRY
+    FR3D_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    FR3D_CATCH
+}
+int fr3d_d2h(void *dst, const void *src, size_t bytes)
+{
+    FR3D_TRY
+    FR3D_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+int fr3d_sync(void)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_HIP(hipStreamSynchronize(g_eng.st));
+    FR3D_CATCH
+}
+
+// ---- measurement --------------------------------------------------------------------------------
+
+static void fold_spans()
+{
+    Engine &e = g_eng;
+    if (e.spans.empty()) return;
+    FR3D_HIP(hipStreamSynchronize(e.st));
+    for (auto &s : e.spans) {
+        float ms = 0.0f;
+        FR3D_HIP(hipEventElapsedTime(&ms, s.a, s.b));
+        e.acc[s.kid].ms += ms;
+        e.ev_pool.push_back(s.a);
+        e.ev_pool.push_back(s.b);
+    }
+    e.spans.clear();
+}
+
+int fr3d_prof_enable(int on)
+{
+    FR3D_TRY
+    ensure_init();
+    fold_spans();
+    g_eng.prof = on != 0;
+    FR3D_CATCH
+}
+int fr3d_prof_reset(void)
+{
+    FR3D_TRY
+    ensure_init();
+    fold_spans();
+    std::memset(g_eng.acc, 0, sizeof(g_eng.acc));
+    FR3D_CATCH
+}
+int fr3d_prof_get(fr3d_kernel_stat *out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(out, "NULL pointer");
+    fold_spans();
+    std::memcpy(out, g_eng.acc, sizeof(g_eng.acc));
+    FR3D_CATCH
+}
+
+}  // extern "C"

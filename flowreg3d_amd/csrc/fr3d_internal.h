@@ -1,0 +1,128 @@
+// fr3d_internal.h -- shared declarations of the gfx950 engine (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/flowreg3d_hip.h"
+
+namespace fr3d {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define FR3D_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            throw ::fr3d::Error(std::string(#expr) + ": " + hipGetErrorString(e__) + " (" +      \
+                                __FILE__ + ":" + std::to_string(__LINE__) + ")");               \
+    } while (0)
+
+#define FR3D_CHECK(cond, msg)                                                                   \
+    do {                                                                                        \
+        if (!(cond)) throw ::fr3d::Error(std::string(msg));                                     \
+    } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// Skewed ("hyperplane-major") layout used by the SOR sweep.
+//
+// Interior voxel (k,j,i) = (z,y,x) of a level lives at  s*plane + k*Yp + j  with s = i+j+k.
+// All voxels of one lexicographic-Gauss-Seidel wavefront (constant s) are then contiguous in j
+// for fixed k, and the six stencil neighbours are at constant offsets:
+//   (k,j,i-1) -> -plane      (k,j-1,i) -> -plane-1     (k-1,j,i) -> -plane-Yp
+//   (k,j,i+1) -> +plane      (k,j+1,i) -> +plane+1     (k+1,j,i) -> +plane+Yp
+// Storage is S*Z*Yp elements (S = X+Y+Z-2 hyperplanes): ~3x the voxel count for a cube; only the
+// valid third is ever touched, so it costs HBM capacity (288 GB), not bandwidth.
+// ---------------------------------------------------------------------------------------------
+struct Skew {
+    int Z, Y, X;
+    int Yp;           // row pitch (Y rounded up to 64 elements)
+    int S;            // number of hyperplanes
+    long long plane;  // Z*Yp
+    long long total;  // S*plane
+};
+
+static inline Skew make_skew(int Z, int Y, int X)
+{
+    Skew k;
+    k.Z = Z; k.Y = Y; k.X = X;
+    k.Yp = ((Y + 63) / 64) * 64;
+    k.S = X + Y + Z - 2;
+    k.plane = (long long)Z * k.Yp;
+    k.total = (long long)k.S * k.plane;
+    return k;
+}
+
+struct SorArgs {
+    // per channel c: J[a*FR3D_MAX_CHANNELS + c], a in 0..8 = J11,J22,J33,J12,J13,J23,J14,J24,J34
+    const float *J[9 * FR3D_MAX_CHANNELS];
+    // square-root factors of the motion tensor, A[q*FR3D_MAX_CHANNELS + c], q = 4*k + a
+    // (k = x,y,z equation; a = u,v,w,t column): J = sum_k a_k a_k^T.  Read on psi-update iterations.
+    const float *A[12 * FR3D_MAX_CHANNELS];
+    const float *weight[FR3D_MAX_CHANNELS];
+    float *wpsi[FR3D_MAX_CHANNELS];
+    const float *L[3];  // alpha-weighted Laplacian of u,v,w (constant over the iterations)
+    float *d[3];        // du,dv,dw, updated in place
+    Skew sk;
+    double ax, ay, az;  // alpha/h^2
+    double a_data[FR3D_MAX_CHANNELS];
+    int C;
+    int iterations, update_lag;
+};
+
+// ---- launchers (each enqueues on `st`, no synchronisation) ------------------------------------
+
+// K1 resample: one separable pass.  src element (a,b,c) at ((a*n1+b)*n2+c)*cs+co ; dst planar.
+// axis 2 = x (innermost), 1 = y, 0 = z.
+void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0, int n1, int n2,
+                        int axis, int out_len, const int *idx, const float *wt, int P, float *dst);
+
+// K2 warp
+template <typename T>
+void launch_pad_edge(hipStream_t st, const T *src, int cs, int co, int Z, int Y, int X, int npad,
+                     double *dst);
+void launch_prefilter3(hipStream_t st, double *c, int PZ, int PY, int PX);
+// flow components pu/pv/pw with element stride fs; displacement = value / h (per axis)
+template <typename TF, typename TR>
+void launch_warp_cubic(hipStream_t st, const double *coef, int npad, const TF *pu, const TF *pv,
+                       const TF *pw, int fs, double hx, double hy, double hz, const TR *ref,
+                       int rcs, int rco, int Z, int Y, int X, float *out, int ocs, int oco);
+template <typename TV, typename TF>
+void launch_warp_linear(hipStream_t st, const TV *vol, int vcs, int vco, const TF *pu,
+                        const TF *pv, const TF *pw, int fs, const TV *ref, int Z, int Y, int X,
+                        float *out, int ocs, int oco);
+
+// K3 motion tensor: f1,f2 planar (Z,Y,X) fp32.  Jout[a] for a = J11,J22,J33,J44,J12,J13,J23,
+// J14,J24,J34; A (nullable): 12 factor arrays a_stride apart; written skewed (sk != nullptr) or
+// natural.
+void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int Z, int Y, int X,
+                          double hz, double hy, double hx, float *const Jout[10], float *A,
+                          long long a_stride, const Skew *sk);
+
+// K4-K7 SOR
+void launch_skew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst);
+void launch_unskew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst);
+void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
+                    double ax, double ay, double az, float *Lu, float *Lv, float *Lw);
+// Runs all `iterations` pipelined hyperplane steps.  Returns the number of kernel launches.
+long long launch_sor(hipStream_t st, const SorArgs &a, bool fp64);
+
+// K8 median (natural layout)
+void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);
+
+// K9 pointwise helpers
+void launch_axpy(hipStream_t st, float *y, const float *x, long long n);  // y += x
+void launch_fill(hipStream_t st, float *y, float v, long long n);
+// interleave/deinterleave between (n,C) channels-last and planar (C,n)
+void launch_pack(hipStream_t st, const float *planar, int C, long long n, float *interleaved);
+void launch_unpack(hipStream_t st, const float *interleaved, int C, long long n, float *planar);
+
+}  // namespace fr3d

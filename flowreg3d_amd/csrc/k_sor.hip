@@ -1,0 +1,272 @@
+// k_sor.hip -- K4+K6+K7: the lagged-nonlinearity SOR inner solver
+// (core/level_solver_3d.py:314-546, a_smooth == 1 branch :472-493), lexicographic-exact.
+//
+// The reference sweeps voxels in lexicographic k->j->i order (true Gauss-Seidel: a voxel sees the
+// NEW values of (k-1,j,i),(k,j-1,i),(k,j,i-1) and the OLD values of the +1 neighbours).  All voxels
+// on a hyperplane s = i+j+k are mutually independent under that order, and iteration t+1 may
+// process hyperplane s-2 while iteration t processes s.  One kernel launch therefore advances every
+// in-flight iteration by one hyperplane:  launch tau handles {(t, s = tau - 2t)} -- up to
+// `iterations` hyperplanes at once -- and reproduces the sequential sweep exactly (same
+// neighbour states), with S + 2(iterations-1) launches per level instead of iterations*S.
+//
+// Data sits in the skewed layout of fr3d_internal.h, so a wave reads/writes contiguous j-runs
+// and the six neighbours are constant offsets.  Per voxel update the kernel streams
+// 9C tensor entries + C (w*psi) + 3 Laplacian terms + 3 increments and writes 3 increments:
+// 4*(10C+9) algorithmic bytes (76 B for C = 1).  On psi-update iterations (every update_lag-th)
+// it reads the 12C square-root factors + C weights instead of the 9C entries + C (w*psi).
+//
+// Fusions: the Neumann ghost copy set_boundary_3d (:246-259) becomes "a missing neighbour is the
+// voxel's own old value"; the psi_data update (:356-377) is pointwise in the old increment, so it
+// is evaluated inside the sweep on iterations with t % update_lag == 0 and stored as w*psi;
+// the u,v,w part of the stencil is iteration-invariant and precomputed once (k_laplace).
+#include "fr3d_internal.h"
+
+namespace fr3d {
+
+#define SOR_OMEGA 1.95
+#define SOR_BX 64
+#define SOR_BY 4
+
+template <typename R> __device__ __forceinline__ R fma_(R a, R b, R c);
+template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
+
+template <typename R, int C>
+__global__ void __launch_bounds__(SOR_BX * SOR_BY)
+k_sor_step(const SorArgs a, int tau, int t_lo)
+{
+    const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X, Yp = a.sk.Yp;
+    const long long plane = a.sk.plane;
+    const int t = t_lo + blockIdx.z;
+    const int s = tau - 2 * t;
+    const int k = blockIdx.y * SOR_BY + threadIdx.y;
+    const int j = blockIdx.x * SOR_BX + threadIdx.x;
+    if (k >= Z || j >= Y) return;
+    const int i = s - k - j;
+    if (i < 0 || i >= X) return;
+
+    const size_t c0 = (size_t)((long long)s * plane + (long long)k * Yp + j);
+    const R du0 = (R)a.d[0][c0], dv0 = (R)a.d[1][c0], dw0 = (R)a.d[2][c0];
+
+    // neighbour sums; a ghost neighbour holds the voxel's own old value (set_boundary_3d)
+    R su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z;
+    {
+        const bool hm = i > 0, hp = i < X - 1;
+        const size_t m = c0 - (size_t)plane, p = c0 + (size_t)plane;
+        su_x = (hm ? (R)a.d[0][m] : du0) + (hp ? (R)a.d[0][p] : du0);
+        sv_x = (hm ? (R)a.d[1][m] : dv0) + (hp ? (R)a.d[1][p] : dv0);
+        sw_x = (hm ? (R)a.d[2][m] : dw0) + (hp ? (R)a.d[2][p] : dw0);
+    }
+    {
+        const bool hm = j > 0, hp = j < Y - 1;
+        const size_t m = c0 - (size_t)plane - 1, p = c0 + (size_t)plane + 1;
+        su_y = (hm ? (R)a.d[0][m] : du0) + (hp ? (R)a.d[0][p] : du0);
+        sv_y = (hm ? (R)a.d[1][m] : dv0) + (hp ? (R)a.d[1][p] : dv0);
+        sw_y = (hm ? (R)a.d[2][m] : dw0) + (hp ? (R)a.d[2][p] : dw0);
+    }
+    {
+        const bool hm = k > 0, hp = k < Z - 1;
+        const size_t m = c0 - (size_t)plane - Yp, p = c0 + (size_t)plane + Yp;
+        su_z = (hm ? (R)a.d[0][m] : du0) + (hp ? (R)a.d[0][p] : du0);
+        sv_z = (hm ? (R)a.d[1][m] : dv0) + (hp ? (R)a.d[1][p] : dv0);
+        sw_z = (hm ? (R)a.d[2][m] : dw0) + (hp ? (R)a.d[2][p] : dw0);
+    }
+    const R ax = (R)a.ax, ay = (R)a.ay, az = (R)a.az;
+    R num_u = fma_<R>(az, su_z, fma_<R>(ay, su_y, fma_<R>(ax, su_x, (R)a.L[0][c0])));
+    R num_v = fma_<R>(az, sv_z, fma_<R>(ay, sv_y, fma_<R>(ax, sv_x, (R)a.L[1][c0])));
+    R num_w = fma_<R>(az, sw_z, fma_<R>(ay, sw_y, fma_<R>(ax, sw_x, (R)a.L[2][c0])));
+    const R diag = (R)(2.0 * a.ax + 2.0 * a.ay + 2.0 * a.az);
+    R den_u = diag, den_v = diag, den_w = diag;
+
+    const bool upd = (t % a.update_lag) == 0;
+    R j12[C], j13[C], j23[C], ww[C];
+    R bu = 0, bv = 0, bw = 0;  // sum_c ww*J14, ww*J24, ww*J34
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        R J11, J22, J33, J12, J13, J23, J14, J24, J34, w;
+        if (upd) {
+            // psi_data update (level_solver_3d.py:356-377) from the increments of iteration t-1.
+            // The quadratic form is evaluated as the sum of three squared residuals of the tensor's
+            // square-root factors (see k_tensor.hip) -- algebraically the reference's expression,
+            // but stable with fp32 storage -- and the nine tensor entries this iteration needs are
+            // rebuilt from the same factors instead of being read.
+            float f[12];
+#pragma unroll
+            for (int q = 0; q < 12; q++) f[q] = a.A[q * FR3D_MAX_CHANNELS + c][c0];
+            double wt = (double)a.weight[c][c0];
+            const double adc = a.a_data[c];
+            if (adc != 1.0) {
+                const double u_ = (double)du0, v_ = (double)dv0, w_ = (double)dw0;
+                double val = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double r = fma((double)f[4 * k], u_, fma((double)f[4 * k + 1], v_,
+                                   fma((double)f[4 * k + 2], w_, (double)f[4 * k + 3])));
+                    val = fma(r, r, val);
+                }
+                wt *= adc * pow(val + 1e-6, adc - 1.0);
+            }
+            const float wf = (float)wt;
+            a.wpsi[c][c0] = wf;
+            w = (R)wf;
+            const R x0 = (R)f[0], x1 = (R)f[1], x2 = (R)f[2], x3 = (R)f[3];
+            const R y0 = (R)f[4], y1 = (R)f[5], y2 = (R)f[6], y3 = (R)f[7];
+            const R z0 = (R)f[8], z1 = (R)f[9], z2 = (R)f[10], z3 = (R)f[11];
+            J11 = fma_<R>(z0, z0, fma_<R>(y0, y0, x0 * x0));
+            J22 = fma_<R>(z1, z1, fma_<R>(y1, y1, x1 * x1));
+            J33 = fma_<R>(z2, z2, fma_<R>(y2, y2, x2 * x2));
+            J12 = fma_<R>(z0, z1, fma_<R>(y0, y1, x0 * x1));
+            J13 = fma_<R>(z0, z2, fma_<R>(y0, y2, x0 * x2));
+            J23 = fma_<R>(z1, z2, fma_<R>(y1, y2, x1 * x2));
+            J14 = fma_<R>(z0, z3, fma_<R>(y0, y3, x0 * x3));
+            J24 = fma_<R>(z1, z3, fma_<R>(y1, y3, x1 * x3));
+            J34 = fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3));
+        } else {
+            J11 = (R)a.J[0 * FR3D_MAX_CHANNELS + c][c0];
+            J22 = (R)a.J[1 * FR3D_MAX_CHANNELS + c][c0];
+            J33 = (R)a.J[2 * FR3D_MAX_CHANNELS + c][c0];
+            J12 = (R)a.J[3 * FR3D_MAX_CHANNELS + c][c0];
+            J13 = (R)a.J[4 * FR3D_MAX_CHANNELS + c][c0];
+            J23 = (R)a.J[5 * FR3D_MAX_CHANNELS + c][c0];
+            J14 = (R)a.J[6 * FR3D_MAX_CHANNELS + c][c0];
+            J24 = (R)a.J[7 * FR3D_MAX_CHANNELS + c][c0];
+            J34 = (R)a.J[8 * FR3D_MAX_CHANNELS + c][c0];
+            w = (R)a.wpsi[c][c0];
+        }
+        ww[c] = w;
+        j12[c] = J12; j13[c] = J13; j23[c] = J23;
+        den_u = fma_<R>(w, J11, den_u);
+        den_v = fma_<R>(w, J22, den_v);
+        den_w = fma_<R>(w, J33, den_w);
+        bu = fma_<R>(w, J14, bu);
+        bv = fma_<R>(w, J24, bv);
+        bw = fma_<R>(w, J34, bw);
+    }
+
+    const R om = (R)SOR_OMEGA, om1 = (R)(1.0 - SOR_OMEGA);
+    // du (uses old dv, dw)
+    R n2 = num_u - bu;
+#pragma unroll
+    for (int c = 0; c < C; c++) n2 -= ww[c] * fma_<R>(j13[c], dw0, j12[c] * dv0);
+    const R du1 = fma_<R>(om, (den_u != (R)0 ? n2 / den_u : (R)0), om1 * du0);
+    // dv (uses new du, old dw)
+    n2 = num_v - bv;
+#pragma unroll
+    for (int c = 0; c < C; c++) n2 -= ww[c] * fma_<R>(j23[c], dw0, j12[c] * du1);
+    const R dv1 = fma_<R>(om, (den_v != (R)0 ? n2 / den_v : (R)0), om1 * dv0);
+    // dw (uses new du, dv)
+    n2 = num_w - bw;
+#pragma unroll
+    for (int c = 0; c < C; c++) n2 -= ww[c] * fma_<R>(j23[c], dv1, j13[c] * du1);
+    const R dw1 = fma_<R>(om, (den_w != (R)0 ? n2 / den_w : (R)0), om1 * dw0);
+
+    a.d[0][c0] = (float)du1;
+    a.d[1][c0] = (float)dv1;
+    a.d[2][c0] = (float)dw1;
+}
+
+template <typename R>
+static void launch_step(hipStream_t st, const SorArgs &a, int tau, int t_lo, int nt)
+{
+    dim3 grid(cdiv(a.sk.Y, SOR_BX), cdiv(a.sk.Z, SOR_BY), nt), block(SOR_BX, SOR_BY);
+    switch (a.C) {
+        case 1: hipLaunchKernelGGL((k_sor_step<R, 1>), grid, block, 0, st, a, tau, t_lo); break;
+        case 2: hipLaunchKernelGGL((k_sor_step<R, 2>), grid, block, 0, st, a, tau, t_lo); break;
+        case 3: hipLaunchKernelGGL((k_sor_step<R, 3>), grid, block, 0, st, a, tau, t_lo); break;
+        case 4: hipLaunchKernelGGL((k_sor_step<R, 4>), grid, block, 0, st, a, tau, t_lo); break;
+        default: throw Error("SOR kernel is instantiated for 1..4 channels");
+    }
+}
+
+long long launch_sor(hipStream_t st, const SorArgs &a, bool fp64)
+{
+    const int S = a.sk.S, T = a.iterations;
+    if (T <= 0) return 0;
+    long long launches = 0;
+    const int last = (S - 1) + 2 * (T - 1);
+    for (int tau = 0; tau <= last; tau++) {
+        int t_lo = tau - (S - 1);
+        t_lo = t_lo <= 0 ? 0 : (t_lo + 1) / 2;
+        int t_hi = tau / 2;
+        if (t_hi > T - 1) t_hi = T - 1;
+        if (t_lo > t_hi) continue;
+        if (fp64) launch_step<double>(st, a, tau, t_lo, t_hi - t_lo + 1);
+        else launch_step<float>(st, a, tau, t_lo, t_hi - t_lo + 1);
+        launches++;
+    }
+    return launches;
+}
+
+// ---- layout conversion and the iteration-invariant stencil part -------------------------------
+
+__global__ void __launch_bounds__(256)
+k_skew_copy(const float *__restrict__ src, int Z, int Y, int X, int Yp, long long plane,
+            float *__restrict__ dst, int to_skew)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)Z * Y * X;
+    if (t >= total) return;
+    int x = (int)(t % X);
+    long long r = t / X;
+    int y = (int)(r % Y);
+    int z = (int)(r / Y);
+    size_t o = (size_t)((long long)(x + y + z) * plane + (long long)z * Yp + y);
+    if (to_skew) dst[o] = src[t];
+    else dst[t] = src[o];
+}
+
+void launch_skew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst)
+{
+    long long total = (long long)sk.Z * sk.Y * sk.X;
+    hipLaunchKernelGGL(k_skew_copy, dim3(cdiv(total, 256)), dim3(256), 0, st, src, sk.Z, sk.Y, sk.X,
+                       sk.Yp, sk.plane, dst, 1);
+}
+
+void launch_unskew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst)
+{
+    long long total = (long long)sk.Z * sk.Y * sk.X;
+    hipLaunchKernelGGL(k_skew_copy, dim3(cdiv(total, 256)), dim3(256), 0, st, src, sk.Z, sk.Y, sk.X,
+                       sk.Yp, sk.plane, dst, 0);
+}
+
+// L = ax*(u_ip + u_im - 2u) + ay*(...) + az*(...) with edge-padded u (add_boundary,
+// core/optical_flow_3d.py:88), evaluated in fp64 from the fp32-exact level flow.
+__global__ void __launch_bounds__(256)
+k_laplace(const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w,
+          int Z, int Y, int X, int Yp, long long plane, double ax, double ay, double az,
+          float *__restrict__ Lu, float *__restrict__ Lv, float *__restrict__ Lw)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)Z * Y * X;
+    if (t >= total) return;
+    int x = (int)(t % X);
+    long long r = t / X;
+    int y = (int)(r % Y);
+    int z = (int)(r / Y);
+    const long long sx = 1, sy = X, sz = (long long)Y * X;
+    const long long xm = x > 0 ? -sx : 0, xp = x < X - 1 ? sx : 0;
+    const long long ym = y > 0 ? -sy : 0, yp = y < Y - 1 ? sy : 0;
+    const long long zm = z > 0 ? -sz : 0, zp = z < Z - 1 ? sz : 0;
+    size_t o = (size_t)((long long)(x + y + z) * plane + (long long)z * Yp + y);
+    const float *f[3] = {u, v, w};
+    float *L[3] = {Lu, Lv, Lw};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float *q = f[d] + t;
+        double c = (double)q[0];
+        double acc = ax * ((double)q[xp] + (double)q[xm] - 2.0 * c);
+        acc += ay * ((double)q[yp] + (double)q[ym] - 2.0 * c);
+        acc += az * ((double)q[zp] + (double)q[zm] - 2.0 * c);
+        L[d][o] = (float)acc;
+    }
+}
+
+void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
+                    double ax, double ay, double az, float *Lu, float *Lv, float *Lw)
+{
+    long long total = (long long)sk.Z * sk.Y * sk.X;
+    hipLaunchKernelGGL(k_laplace, dim3(cdiv(total, 256)), dim3(256), 0, st, u, v, w, sk.Z, sk.Y,
+                       sk.X, sk.Yp, sk.plane, ax, ay, az, Lu, Lv, Lw);
+}
+
+}  // namespace fr3d

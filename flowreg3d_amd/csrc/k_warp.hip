@@ -1,0 +1,400 @@
+// k_warp.hip -- K2: backward warp = scipy.ndimage.map_coordinates(order in {1,3}, mode="nearest")
+// as imregister_wrapper uses it (core/optical_flow_3d.py:22-74).
+//
+// order 3 follows SciPy 1.15 step by step, in fp64 like SciPy:
+//   1. edge-pad the volume by 12 voxels           (_interpolation.py _prepad_for_spline_filter)
+//   2. cubic B-spline prefilter along z, y, x     (ni_splines.c apply_filter: gain 6, pole
+//      sqrt(3)-2, mode 'nearest' -> half-sample-symmetric initialisation, in-place quirk kept)
+//   3. 4x4x4 gather with fp32 coordinates         (ni_interpolation.c NI_GeometricTransform)
+// Each warp is done once per pyramid level, so it is kept reference-exact (fp64 coefficients)
+// rather than minimal in bytes; the bandwidth-critical kernel of the path is the SOR sweep.
+#include "fr3d_internal.h"
+
+namespace fr3d {
+
+#define SPL_POLE (-0.26794919243112270647)  // sqrt(3) - 2
+
+__device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+// ---- 1. edge pad ------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pad_edge(const T *__restrict__ src, int cs, int co, int Z, int Y, int X, int npad,
+           double *__restrict__ dst)
+{
+    const int PZ = Z + 2 * npad, PY = Y + 2 * npad, PX = X + 2 * npad;
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)PZ * PY * PX;
+    if (t >= total) return;
+    int x = (int)(t % PX);
+    long long r = t / PX;
+    int y = (int)(r % PY);
+    int z = (int)(r / PY);
+    int sz = clampi(z - npad, Z), sy = clampi(y - npad, Y), sx = clampi(x - npad, X);
+    dst[t] = (double)src[(((size_t)sz * Y + sy) * X + sx) * cs + co];
+}
+
+template <typename T>
+void launch_pad_edge(hipStream_t st, const T *src, int cs, int co, int Z, int Y, int X, int npad,
+                     double *dst)
+{
+    long long total = (long long)(Z + 2 * npad) * (Y + 2 * npad) * (X + 2 * npad);
+    hipLaunchKernelGGL(k_pad_edge<T>, dim3(cdiv(total, 256)), dim3(256), 0, st, src, cs, co, Z, Y,
+                       X, npad, dst);
+}
+template void launch_pad_edge<float>(hipStream_t, const float *, int, int, int, int, int, int, double *);
+template void launch_pad_edge<double>(hipStream_t, const double *, int, int, int, int, int, int, double *);
+
+// ---- 2. prefilter -----------------------------------------------------------------------------
+// One line in place.  `c` points at element 0, consecutive elements are `stride` apart.
+// Same operation order as the CPU restatement: gain folded into the first touch of each sample.
+__device__ __forceinline__ void spline_line(double *c, int n, long long stride, double z_n)
+{
+    const double z = SPL_POLE;
+    const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+    // causal initialisation (reflect), sum truncated after 64 terms (|z|^64 < 1e-36)
+    const int lim = n < 64 ? n : 64;
+    double x0 = c[0] * gain;
+    double acc = x0 + z_n * (c[(long long)(n - 1) * stride] * gain);
+    double z_i = z;
+    for (int i = 1; i < lim; i++) {
+        double xi = c[(long long)i * stride] * gain;
+        double xr = (i == n - 1) ? acc : c[(long long)(n - 1 - i) * stride] * gain;
+        acc += z_i * (xi + z_n * xr);
+        z_i *= z;
+    }
+    acc *= z / (1.0 - z_n * z_n);
+    acc += x0;
+    c[0] = acc;
+    double prev = acc;
+    for (int i = 1; i < n; i++) {
+        double xi = c[(long long)i * stride] * gain;
+        xi += z * prev;
+        c[(long long)i * stride] = xi;
+        prev = xi;
+    }
+    prev *= z / (z - 1.0);
+    c[(long long)(n - 1) * stride] = prev;
+    for (int i = n - 2; i >= 0; i--) {
+        double v = z * (prev - c[(long long)i * stride]);
+        c[(long long)i * stride] = v;
+        prev = v;
+    }
+}
+
+// lines enumerated as (outer, inner); element 0 of a line at outer*outer_stride + inner*inner_stride
+__global__ void __launch_bounds__(256)
+k_prefilter_lines(double *c, long long nlines, long long inner_n, long long inner_stride,
+                  long long outer_stride, int n, long long stride, double z_n)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlines) return;
+    long long inner = t % inner_n, outer = t / inner_n;
+    spline_line(c + outer * outer_stride + inner * inner_stride, n, stride, z_n);
+}
+
+// x axis, n > 64: one wave per 64 rows, rows staged through a 64x32 fp64 LDS tile so that global
+// accesses are 256-B row segments while each lane walks its own row in LDS.
+#define PF_TW 32
+__global__ void __launch_bounds__(64)
+k_prefilter_x_tiled(double *c, long long nrows, int n)
+{
+    __shared__ double tile[64][PF_TW + 1];
+    const double z = SPL_POLE;
+    const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+    const int lane = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * 64;
+    const int ntiles = (n + PF_TW - 1) / PF_TW;
+    const int lr = lane >> 5, lc = lane & 31;  // 2 rows x 32 columns per wave-load
+
+    auto load_tile = [&](int t) {
+        int col = t * PF_TW + lc;
+        for (int r = 0; r < 64; r += 2) {
+            long long row = row0 + r + lr;
+            double v = 0.0;
+            if (row < nrows && col < n) v = c[row * n + col];
+            tile[r + lr][lc] = v;
+        }
+    };
+    auto store_tile = [&](int t) {
+        int col = t * PF_TW + lc;
+        for (int r = 0; r < 64; r += 2) {
+            long long row = row0 + r + lr;
+            if (row < nrows && col < n) c[row * n + col] = tile[r + lr][lc];
+        }
+    };
+
+    // causal initialisation from the first 64 samples (two tiles)
+    double x0 = 0.0, acc = 0.0, z_i = z;
+    for (int t = 0; t < 2; t++) {
+        __syncthreads();
+        load_tile(t);
+        __syncthreads();
+        for (int q = 0; q < PF_TW; q++) {
+            int i = t * PF_TW + q;
+            double xi = tile[lane][q] * gain;
+            if (i == 0) {
+                x0 = xi;
+                acc = xi;
+            } else {
+                acc += z_i * xi;
+                z_i *= z;
+            }
+        }
+    }
+    acc *= z;  // z / (1 - z_n^2) with z_n^2 == 0 in fp64 for n > 64
+    acc += x0;
+
+    // causal sweep
+    double prev = acc;
+    for (int t = 0; t < ntiles; t++) {
+        __syncthreads();
+        load_tile(t);
+        __syncthreads();
+        int qn = n - t * PF_TW;
+        if (qn > PF_TW) qn = PF_TW;
+        for (int q = 0; q < qn; q++) {
+            double xi;
+            if (t == 0 && q == 0) {
+                xi = acc;
+            } else {
+                xi = tile[lane][q] * gain;
+                xi += z * prev;
+            }
+            tile[lane][q] = xi;
+            prev = xi;
+        }
+        __syncthreads();
+        store_tile(t);
+    }
+    // anticausal sweep
+    for (int t = ntiles - 1; t >= 0; t--) {
+        __syncthreads();
+        load_tile(t);
+        __syncthreads();
+        int qn = n - t * PF_TW;
+        if (qn > PF_TW) qn = PF_TW;
+        for (int q = qn - 1; q >= 0; q--) {
+            double v;
+            if (t == ntiles - 1 && q == qn - 1) {
+                v = tile[lane][q] * (z / (z - 1.0));
+            } else {
+                v = z * (prev - tile[lane][q]);
+            }
+            tile[lane][q] = v;
+            prev = v;
+        }
+        __syncthreads();
+        store_tile(t);
+    }
+}
+
+static double zpow(int n) { return pow(SPL_POLE, (double)n); }
+
+void launch_prefilter3(hipStream_t st, double *c, int PZ, int PY, int PX)
+{
+    // axis 0 (z): lines over (y,x), stride PY*PX
+    if (PZ > 1) {
+        long long nl = (long long)PY * PX;
+        hipLaunchKernelGGL(k_prefilter_lines, dim3(cdiv(nl, 256)), dim3(256), 0, st, c, nl, nl,
+                           1LL, 0LL, PZ, (long long)PY * PX, zpow(PZ));
+    }
+    // axis 1 (y): lines over (z,x), stride PX
+    if (PY > 1) {
+        long long nl = (long long)PZ * PX;
+        hipLaunchKernelGGL(k_prefilter_lines, dim3(cdiv(nl, 256)), dim3(256), 0, st, c, nl,
+                           (long long)PX, 1LL, (long long)PY * PX, PY, (long long)PX, zpow(PY));
+    }
+    // axis 2 (x): contiguous lines
+    if (PX > 1) {
+        long long nl = (long long)PZ * PY;
+        if (PX > 64) {
+            hipLaunchKernelGGL(k_prefilter_x_tiled, dim3(cdiv(nl, 64)), dim3(64), 0, st, c, nl, PX);
+        } else {
+            hipLaunchKernelGGL(k_prefilter_lines, dim3(cdiv(nl, 256)), dim3(256), 0, st, c, nl, nl,
+                               (long long)PX, 0LL, PX, 1LL, zpow(PX));
+        }
+    }
+}
+
+// ---- 3. gather --------------------------------------------------------------------------------
+// ni_splines.c get_spline_interpolation_weights(), order 3
+__device__ __forceinline__ void bspline3_weights(double cc, double *w, int *start)
+{
+    double fl = floor(cc);
+    *start = (int)fl - 1;
+    double x = cc - fl;
+    double z = 1.0 - x;
+    w[1] = (x * x * (x - 2.0) * 3.0 + 4.0) / 6.0;
+    w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
+    w[0] = z * z * z / 6.0;
+    double w3 = 1.0;
+    w3 -= w[0];
+    w3 -= w[1];
+    w3 -= w[2];
+    w[3] = w3;
+}
+
+template <typename TF, typename TR>
+__global__ void __launch_bounds__(256)
+k_warp_cubic(const double *__restrict__ coef, int npad, const TF *__restrict__ pu,
+             const TF *__restrict__ pv, const TF *__restrict__ pw, int fs, double hx, double hy,
+             double hz, const TR *__restrict__ ref, int rcs, int rco, int Z, int Y, int X,
+             float *__restrict__ out, int ocs, int oco)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)Z * Y * X;
+    if (t >= total) return;
+    int x = (int)(t % X);
+    long long r = t / X;
+    int y = (int)(r % Y);
+    int z = (int)(r / Y);
+    // core/optical_flow_3d.py:32-34 : (grid + displacement).astype(float32)
+    float mx = (float)((double)x + (double)pu[(size_t)t * fs] / hx);
+    float my = (float)((double)y + (double)pv[(size_t)t * fs] / hy);
+    float mz = (float)((double)z + (double)pw[(size_t)t * fs] / hz);
+    bool oob = (mx < 0.0f) || (mx >= (float)X) || (my < 0.0f) || (my >= (float)Y) ||
+               (mz < 0.0f) || (mz >= (float)Z);
+    if (oob) {
+        out[(size_t)t * ocs + oco] = (float)ref[(size_t)t * rcs + rco];
+        return;
+    }
+    float cx = mx > (float)(X - 1) ? (float)(X - 1) : mx;
+    float cy = my > (float)(Y - 1) ? (float)(Y - 1) : my;
+    float cz = mz > (float)(Z - 1) ? (float)(Z - 1) : mz;
+    const int PY = Y + 2 * npad, PX = X + 2 * npad, PZ = Z + 2 * npad;
+    double wz[4], wy[4], wx[4];
+    int sz, sy, sx;
+    bspline3_weights((double)cz + npad, wz, &sz);
+    bspline3_weights((double)cy + npad, wy, &sy);
+    bspline3_weights((double)cx + npad, wx, &sx);
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        int zi = clampi(sz + a, PZ);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int yi = clampi(sy + b, PY);
+            const double *row = coef + ((size_t)zi * PY + yi) * PX;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int xi = clampi(sx + e, PX);
+                double cf = row[xi];
+                cf *= wz[a];
+                cf *= wy[b];
+                cf *= wx[e];
+                acc += cf;
+            }
+        }
+    }
+    out[(size_t)t * ocs + oco] = (float)acc;
+}
+
+template <typename TF, typename TR>
+void launch_warp_cubic(hipStream_t st, const double *coef, int npad, const TF *pu, const TF *pv,
+                       const TF *pw, int fs, double hx, double hy, double hz, const TR *ref,
+                       int rcs, int rco, int Z, int Y, int X, float *out, int ocs, int oco)
+{
+    long long total = (long long)Z * Y * X;
+    hipLaunchKernelGGL((k_warp_cubic<TF, TR>), dim3(cdiv(total, 256)), dim3(256), 0, st, coef,
+                       npad, pu, pv, pw, fs, hx, hy, hz, ref, rcs, rco, Z, Y, X, out, ocs, oco);
+}
+template void launch_warp_cubic<float, float>(hipStream_t, const double *, int, const float *,
+                                              const float *, const float *, int, double, double,
+                                              double, const float *, int, int, int, int, int,
+                                              float *, int, int);
+template void launch_warp_cubic<double, float>(hipStream_t, const double *, int, const double *,
+                                               const double *, const double *, int, double, double,
+                                               double, const float *, int, int, int, int, int,
+                                               float *, int, int);
+template void launch_warp_cubic<float, double>(hipStream_t, const double *, int, const float *,
+                                               const float *, const float *, int, double, double,
+                                               double, const double *, int, int, int, int, int,
+                                               float *, int, int);
+template void launch_warp_cubic<double, double>(hipStream_t, const double *, int, const double *,
+                                                const double *, const double *, int, double,
+                                                double, double, const double *, int, int, int, int,
+                                                int, float *, int, int);
+
+// order 1: no prefilter, no padding; taps clamped like mode="nearest"
+template <typename TV, typename TF>
+__global__ void __launch_bounds__(256)
+k_warp_linear(const TV *__restrict__ vol, int vcs, int vco, const TF *__restrict__ pu,
+              const TF *__restrict__ pv, const TF *__restrict__ pw, int fs,
+              const TV *__restrict__ ref, int Z, int Y, int X, float *__restrict__ out, int ocs,
+              int oco)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)Z * Y * X;
+    if (t >= total) return;
+    int x = (int)(t % X);
+    long long r = t / X;
+    int y = (int)(r % Y);
+    int z = (int)(r / Y);
+    float mx = (float)((double)x + (double)pu[(size_t)t * fs]);
+    float my = (float)((double)y + (double)pv[(size_t)t * fs]);
+    float mz = (float)((double)z + (double)pw[(size_t)t * fs]);
+    bool oob = (mx < 0.0f) || (mx >= (float)X) || (my < 0.0f) || (my >= (float)Y) ||
+               (mz < 0.0f) || (mz >= (float)Z);
+    if (oob) {
+        out[(size_t)t * ocs + oco] = (float)ref[(size_t)t * vcs + vco];
+        return;
+    }
+    double cc[3] = {(double)(mz > (float)(Z - 1) ? (float)(Z - 1) : mz),
+                    (double)(my > (float)(Y - 1) ? (float)(Y - 1) : my),
+                    (double)(mx > (float)(X - 1) ? (float)(X - 1) : mx)};
+    int s[3];
+    double w[3][2];
+    for (int d = 0; d < 3; d++) {
+        double fl = floor(cc[d]);
+        s[d] = (int)fl;
+        double f = cc[d] - fl;
+        w[d][0] = 1.0 - f;
+        w[d][1] = 1.0 - w[d][0];
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        int zi = clampi(s[0] + a, Z);
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            int yi = clampi(s[1] + b, Y);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                int xi = clampi(s[2] + e, X);
+                double cf = (double)vol[(((size_t)zi * Y + yi) * X + xi) * vcs + vco];
+                cf *= w[0][a];
+                cf *= w[1][b];
+                cf *= w[2][e];
+                acc += cf;
+            }
+        }
+    }
+    out[(size_t)t * ocs + oco] = (float)acc;
+}
+
+template <typename TV, typename TF>
+void launch_warp_linear(hipStream_t st, const TV *vol, int vcs, int vco, const TF *pu,
+                        const TF *pv, const TF *pw, int fs, const TV *ref, int Z, int Y, int X,
+                        float *out, int ocs, int oco)
+{
+    long long total = (long long)Z * Y * X;
+    hipLaunchKernelGGL((k_warp_linear<TV, TF>), dim3(cdiv(total, 256)), dim3(256), 0, st, vol, vcs,
+                       vco, pu, pv, pw, fs, ref, Z, Y, X, out, ocs, oco);
+}
+template void launch_warp_linear<float, float>(hipStream_t, const float *, int, int, const float *,
+                                               const float *, const float *, int, const float *,
+                                               int, int, int, float *, int, int);
+template void launch_warp_linear<float, double>(hipStream_t, const float *, int, int,
+                                                const double *, const double *, const double *,
+                                                int, const float *, int, int, int, float *, int,
+                                                int);
+template void launch_warp_linear<double, float>(hipStream_t, const double *, int, int,
+                                                const float *, const float *, const float *, int,
+                                                const double *, int, int, int, float *, int, int);
+template void launch_warp_linear<double, double>(hipStream_t, const double *, int, int,
+                                                 const double *, const double *, const double *,
+                                                 int, const double *, int, int, int, float *, int,
+                                                 int);
+
+}  // namespace fr3d

@@ -1,0 +1,76 @@
+"""Deterministic synthetic volumes and motion for tests and bench.py.
+
+Pure NumPy/SciPy, no reference import: smooth dense texture (Gaussian-blurred PCG64 noise plus a
+few Gaussian blobs), ground-truth flow = translation + small rotation about z through the centre
+(closed form of the reference's Translational/Rotational3DFlowAugmentor,
+motion_generation/motion_generators.py:69-180), moving = backward cubic warp of fixed.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy import ndimage
+
+
+def texture(shape, seed=1234, sigma=2.0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vol = ndimage.gaussian_filter(rng.random(shape, dtype=np.float32), sigma, mode="reflect")
+    Z, Y, X = shape
+    zz, yy, xx = np.meshgrid(np.arange(Z, dtype=np.float32), np.arange(Y, dtype=np.float32),
+                             np.arange(X, dtype=np.float32), indexing="ij", sparse=True)
+    vol = (vol - vol.min()) / (vol.max() - vol.min())
+    s = max(Z, 4) / 10.0
+    for _ in range(8):
+        cz, cy, cx = rng.random(3) * np.array([Z, Y, X])
+        vol = vol + 0.5 * np.exp(-((zz - cz) ** 2 + (yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s)).astype(np.float32)
+    vol = (vol - vol.min()) / (vol.max() - vol.min())
+    return vol.astype(np.float32)
+
+
+def flow_gt(shape, translation=(1.7, -1.1, 0.6), rot_deg=1.5, scale=1.0):
+    """(Z,Y,X,3) float32 displacement [dx,dy,dz]: translation + rotation about the z axis."""
+    Z, Y, X = shape
+    yy, xx = np.meshgrid(np.arange(Y, dtype=np.float64), np.arange(X, dtype=np.float64), indexing="ij")
+    th = np.deg2rad(rot_deg * scale)
+    cy, cx = (Y - 1) / 2.0, (X - 1) / 2.0
+    rx = (np.cos(th) - 1.0) * (xx - cx) - np.sin(th) * (yy - cy)
+    ry = np.sin(th) * (xx - cx) + (np.cos(th) - 1.0) * (yy - cy)
+    f = np.empty((Z, Y, X, 3), np.float32)
+    f[..., 0] = (rx + translation[0] * scale)[None]
+    f[..., 1] = (ry + translation[1] * scale)[None]
+    f[..., 2] = translation[2] * scale
+    return f
+
+
+def backward_warp(vol, flow, order=3):
+    """vol sampled at x + flow (same convention as imregister_wrapper)."""
+    Z, Y, X = vol.shape
+    zz, yy, xx = np.meshgrid(np.arange(Z), np.arange(Y), np.arange(X), indexing="ij")
+    coords = [zz + flow[..., 2], yy + flow[..., 1], xx + flow[..., 0]]
+    return ndimage.map_coordinates(vol.astype(np.float64), coords, order=order, mode="nearest").astype(np.float32)
+
+
+def make_pair(shape, seed=1234, channels=1, scale=1.0, cheap=False):
+    """-> fixed, moving (Z,Y,X[,C]) float32 in [0,1] and the ground-truth flow (Z,Y,X,3).
+
+    moving(x) = fixed(x - flow), so get_displacement(fixed, moving) ~ flow.  ``cheap`` uses
+    linear interpolation (fast for 256^3/512^3 bench volumes)."""
+    gt = flow_gt(shape, scale=scale)
+    fs, ms = [], []
+    for c in range(channels):
+        f = texture(shape, seed + c)
+        fs.append(f)
+        ms.append(backward_warp(f, -gt, order=1 if cheap else 3))
+    if channels == 1:
+        return fs[0], ms[0], gt
+    return np.stack(fs, -1), np.stack(ms, -1), gt
+
+
+def epe(a, b, crop=0):
+    """mean / max end-point error between two (Z,Y,X,3) flows, optionally cropped per side."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if crop:
+        s = (slice(crop, -crop),) * 3
+        a, b = a[s], b[s]
+    d = np.linalg.norm(a - b, axis=-1)
+    return float(d.mean()), float(d.max())

@@ -1,0 +1,160 @@
+/*
+ * flowreg3d_hip.h -- C ABI of the MI355X (gfx950) engine behind flowreg3d's
+ * get_displacement / imregister_wrapper / executor.process_batch path.
+ *
+ * The reference is pure Python, so there is no existing FFI to mirror; each entry point names
+ * the reference function (file:line under /root/reference/src/flowreg3d/) whose arithmetic it
+ * replaces and is what a ctypes/cffi binding inside flowreg3d would call.
+ *
+ * Conventions
+ *  - plain C types only; arrays are C-contiguous, channels-last exactly as NumPy hands them:
+ *    volumes (Z,Y,X,C), flow (Z,Y,X,3) with components [dx,dy,dz] = [u,v,w].
+ *  - "_dev" entry points take device pointers (hipMalloc'ed, e.g. torch tensors' data_ptr());
+ *    the others take host pointers and stage through internal device buffers.
+ *  - every function returns 0 on success, non-zero on failure; fr3d_last_error() gives the
+ *    thread-local message.  Nothing is retained from caller pointers after a call returns.
+ *  - all work is issued on one internal HIP stream per process and is complete on return
+ *    unless stated otherwise.  Calls are serialised by an internal mutex (re-entrant safe).
+ */
+#ifndef FLOWREG3D_HIP_H
+#define FLOWREG3D_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FR3D_MAX_CHANNELS 8
+
+/* element types of caller buffers */
+#define FR3D_F32 0
+#define FR3D_F64 1
+
+/* Solver parameters = keyword arguments of get_displacement
+ * (core/optical_flow_3d.py:319-333) as the executors pass them in `flow_params`
+ * (motion_correction/compensate_recording_3D.py:301-315). */
+typedef struct fr3d_params {
+    double alpha[3];                   /* alpha_x, alpha_y, alpha_z */
+    int update_lag;
+    int iterations;
+    int min_level;
+    int levels;
+    double eta;
+    double a_smooth;                   /* only 1.0 is implemented on the device */
+    double a_data[FR3D_MAX_CHANNELS];  /* per channel */
+    int solver_fp64;                   /* 0: fp32 storage + fp32 update arithmetic (default);
+                                          1: fp32 storage, fp64 update arithmetic */
+    int reserved[7];
+} fr3d_params;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int fr3d_init(int device);              /* hipSetDevice + stream + workspace; idempotent */
+void fr3d_shutdown(void);               /* frees every device buffer and the stream */
+const char *fr3d_last_error(void);
+int fr3d_device_count(void);            /* hipGetDeviceCount without initialising a context */
+const char *fr3d_version(void);
+
+/* ---- the hot path --------------------------------------------------------------------- */
+
+/* get_displacement (core/optical_flow_3d.py:319-542): multiscale coarse-to-fine solve.
+ * fixed/moving: (Z,Y,X,C) fp32; uvw_init: (Z,Y,X,3) fp32 or NULL (= zeros);
+ * weight: (Z,Y,X,C) fp32 or NULL (= 1/C); flow_out: (Z,Y,X,3) fp32. */
+int fr3d_get_displacement(const fr3d_params *p, const float *fixed, const float *moving,
+                          int Z, int Y, int X, int C, const float *uvw_init,
+                          const float *weight, float *flow_out);
+int fr3d_get_displacement_dev(const fr3d_params *p, const float *fixed, const float *moving,
+                              int Z, int Y, int X, int C, const float *uvw_init,
+                              const float *weight, float *flow_out);
+
+/* imregister_wrapper (core/optical_flow_3d.py:22-74): backward warp of `vol` by `flow`,
+ * out-of-bounds voxels taken from `ref`.  order 3 = cubic B-spline with SciPy's prefilter,
+ * order 1 = linear.  vol/ref (Z,Y,X,C) of vol_dtype; flow (Z,Y,X,3) of flow_dtype;
+ * out (Z,Y,X,C) fp32. */
+int fr3d_warp(const void *vol, int vol_dtype, const void *flow, int flow_dtype, const void *ref,
+              int Z, int Y, int X, int C, int order, float *out);
+int fr3d_warp_dev(const void *vol, int vol_dtype, const void *flow, int flow_dtype,
+                  const void *ref, int Z, int Y, int X, int C, int order, float *out);
+
+/* Per-volume body of the executors (motion_correction/parallelization/sequential_3d.py:148-175)
+ * for T volumes against one fixed reference: flow = get_displacement(ref_proc, batch_proc[t],
+ * uvw=w_init) ; registered = imregister(batch_raw[t], flow, ref_raw, order).
+ * batch_proc/batch_raw: (T,Z,Y,X,C) fp32; ref_proc/ref_raw: (Z,Y,X,C) fp32;
+ * flows_out: (T,Z,Y,X,3) fp32; registered_out: (T,Z,Y,X,C) fp32.
+ * The fixed-reference pyramid is built once per call.  `progress` (nullable) is called with 1
+ * after each volume (base_3d.py:46 progress_callback). */
+typedef void (*fr3d_progress_fn)(int volumes_done, void *user);
+int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
+                       const float *ref_proc, const float *ref_raw, const float *w_init,
+                       const float *weight, int T, int Z, int Y, int X, int C, int order,
+                       float *flows_out, float *registered_out, fr3d_progress_fn progress,
+                       void *user);
+int fr3d_process_batch_dev(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
+                           const float *ref_proc, const float *ref_raw, const float *w_init,
+                           const float *weight, int T, int Z, int Y, int X, int C, int order,
+                           float *flows_out, float *registered_out, fr3d_progress_fn progress,
+                           void *user);
+
+/* ---- kernel-level entry points (stage parity tests; host pointers) ---------------------- */
+
+/* imresize_fused_gauss_cubic3D (util/resize_util_3D.py:114-156), one fp32 channel. */
+int fr3d_resize3d(const float *src, int D, int H, int W, int od, int oh, int ow, float *dst);
+
+/* get_motion_tensor_gc (core/optical_flow_3d.py:92-152) for one channel.  f1,f2 (Z,Y,X) fp32;
+ * J: 10 x (Z,Y,X) fp32 interior values, order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34.
+ * A (nullable): 12 x (Z,Y,X) fp32 square-root factors a_k = sqrt(reg_k)*(f_kx,f_ky,f_kz,f_kt),
+ * k = x,y,z (index 4k+column), J = sum_k a_k a_k^T -- the form the solver evaluates psi from. */
+int fr3d_motion_tensor(const float *f1, const float *f2, int Z, int Y, int X, double hz,
+                       double hy, double hx, float *J, float *A);
+
+/* level_solver -> compute_flow_3d (core/level_solver_3d.py:314-546), a_smooth == 1.
+ * J: (9,C,Z,Y,X) fp32 interior values, order J11,J22,J33,J12,J13,J23,J14,J24,J34;
+ * A: (12,C,Z,Y,X) fp32 factors as above; weight: (C,Z,Y,X) fp32;
+ * uvw: (3,Z,Y,X) fp32 interior flow (ghosts are the edge pad of optical_flow_3d.py:88);
+ * duvw_out: (3,Z,Y,X) fp32 interior increments. */
+int fr3d_level_solve(const float *J, const float *A, const float *weight, const float *uvw, int Z,
+                     int Y, int X, int C, const double *alpha3, int iterations, int update_lag,
+                     const double *a_data, double hx, double hy, double hz, int solver_fp64,
+                     float *duvw_out);
+
+/* scipy.ndimage.median_filter(size=5^3, mode="mirror") (core/optical_flow_3d.py:517-526). */
+int fr3d_median5(const float *in, int Z, int Y, int X, float *out);
+
+/* Level sizes of the pyramid (core/optical_flow_3d.py:77-85,389-408), coarse -> fine.
+ * sizes: max_out x 3 ints (z,y,x).  Returns the number of solves (>= 1) or -1. */
+int fr3d_schedule(int Z, int Y, int X, double eta, int levels, int min_level, int *sizes,
+                  int max_out, int *min_level_eff);
+
+/* ---- device memory helpers (so a host program needs no other GPU runtime) -------------- */
+void *fr3d_dev_malloc(size_t bytes);
+void fr3d_dev_free(void *p);
+int fr3d_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int fr3d_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int fr3d_sync(void);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+
+/* HIP-event timing of the kernels on the engine's own stream, accumulated since the last
+ * reset.  Kernel ids: */
+#define FR3D_K_SOR 0      /* SOR hyperplane sweep (K4+K6+K7 fused) */
+#define FR3D_K_WARP 1     /* B-spline gather */
+#define FR3D_K_PREFILTER 2
+#define FR3D_K_TENSOR 3
+#define FR3D_K_RESIZE 4
+#define FR3D_K_MEDIAN 5
+#define FR3D_K_OTHER 6
+#define FR3D_K_COUNT 7
+typedef struct fr3d_kernel_stat {
+    double ms;              /* summed event-to-event time */
+    double algo_bytes;      /* algorithmic bytes moved (per-kernel definition) */
+    long long launches;     /* kernel launches inside the timed brackets */
+    long long units;        /* voxel updates / output voxels processed */
+} fr3d_kernel_stat;
+int fr3d_prof_enable(int on);   /* off by default: brackets cost two events per stage */
+int fr3d_prof_reset(void);
+int fr3d_prof_get(fr3d_kernel_stat *out /* FR3D_K_COUNT entries */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

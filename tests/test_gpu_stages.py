@@ -1,0 +1,150 @@
+"""-m gpu: every HIP stage of the hot path against the CPU oracle and the reference's golden
+vectors, through the C ABI (flowreg3d_amd.core -> ctypes -> libflowreg3d_hip.so)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- K1 resample: bit-exact vs oracle (same table code, fp32 sequential accumulation) -----------
+@pytest.mark.parametrize("shape,size", [((18, 22, 26), (11, 15, 17)), ((18, 22, 26), (23, 28, 33)),
+                                        ((18, 22, 26), (18, 30, 13)), ((40, 70, 90), (13, 23, 30)),
+                                        ((5, 6, 7), (5, 6, 7)), ((1, 9, 9), (1, 5, 12))])
+def test_resize_bit_exact_vs_oracle(hip, oracle, shape, size):
+    rng = np.random.default_rng(1)
+    vol = rng.random(shape, dtype=np.float32)
+    got = hip.imresize_fused_gauss_cubic3D(vol, size)
+    want = oracle.imresize_fused_gauss_cubic3D(vol, size)
+    assert got.dtype == np.float32 and got.shape == tuple(size)
+    assert np.array_equal(got, want)
+
+
+def test_resize_vs_reference_golden(hip):
+    g = golden("k1_resize")
+    for name, size in (("down", (11, 15, 17)), ("up", (23, 28, 33)), ("mixed", (18, 30, 13))):
+        got = hip.imresize_fused_gauss_cubic3D(g["vol"], size)
+        # reference tables use NumPy's SIMD expf (<= 1 ulp from libm): few-ulp agreement
+        assert np.abs(got - g[name]).max() < 5e-7
+    got4 = hip.imresize_fused_gauss_cubic3D(g["vol4"], (12, 14, 20))
+    assert got4.dtype == np.float64 and np.abs(got4 - g["down4"]).max() < 5e-7
+
+
+# ---- K2 warp ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["cubic", "linear"])
+def test_warp_vs_reference_golden(hip, method):
+    g = golden("k2_warp")
+    got = hip.imregister_wrapper(g["f2"], g["u"], g["v"], g["w"], g["f1"], method)
+    want = g[method]
+    assert got.dtype == np.float32 and got.shape == want.shape
+    # fp64 coefficients and weights like SciPy; output rounded to fp32 -> at most 1 ulp apart
+    assert np.abs(got - want).max() <= 1.2e-7
+    assert (got != want).mean() < 0.01
+
+
+def test_warp_single_channel_and_f32_inputs(hip, oracle):
+    g = golden("k2_warp")
+    got = hip.imregister_wrapper(g["f2"][..., 0], g["u"], g["v"], g["w"], g["f1"][..., 0])
+    assert got.shape == g["cubic_c1"].shape and np.abs(got - g["cubic_c1"]).max() <= 1.2e-7
+    f2 = g["f2"].astype(np.float32)
+    f1 = g["f1"].astype(np.float32)
+    u, v, w = (g[k].astype(np.float32) for k in "uvw")
+    got = hip.imregister_wrapper(f2, u, v, w, f1, "cubic")
+    want = oracle.imregister_wrapper(f2, u, v, w, f1, "cubic")
+    assert np.abs(got - want).max() <= 1.2e-7
+
+
+def test_warp_long_axis_tiled_prefilter(hip, oracle):
+    # X + 24 > 64 exercises the LDS-tiled x-axis prefilter; short Z exercises the faithful init
+    rng = np.random.default_rng(5)
+    f2 = rng.random((7, 21, 150), dtype=np.float32)
+    f1 = rng.random((7, 21, 150), dtype=np.float32)
+    u, v, w = ((rng.random((7, 21, 150), dtype=np.float32) - 0.5) * 5 for _ in range(3))
+    got = hip.imregister_wrapper(f2, u, v, w, f1)
+    want = oracle.imregister_wrapper(f2, u, v, w, f1)
+    assert np.abs(got - want).max() <= 1.2e-7
+
+
+def test_warp_identity_and_oob(hip):
+    rng = np.random.default_rng(2)
+    vol = rng.random((9, 10, 11), dtype=np.float32)
+    ref = rng.random((9, 10, 11), dtype=np.float32)
+    z = np.zeros((9, 10, 11), np.float32)
+    assert np.abs(hip.imregister_wrapper(vol, z, z, z, ref) - vol).max() < 1e-6
+    big = np.full((9, 10, 11), 100.0, np.float32)
+    assert np.array_equal(hip.imregister_wrapper(vol, big, z, z, ref), ref)  # all out of bounds
+    with pytest.raises(ValueError):
+        hip.imregister_wrapper(vol, z, z, z, ref, "nearest")
+
+
+# ---- K3 motion tensor -------------------------------------------------------------------------------
+def test_motion_tensor_vs_reference_golden(hip):
+    g = golden("k3_tensor")
+    f1 = g["f1"].astype(np.float32)
+    f2 = g["f2"].astype(np.float32)
+    assert np.array_equal(f1, g["f1"]) and np.array_equal(f2, g["f2"])  # fixtures are fp32-exact
+    J = hip.get_motion_tensor_gc(f1, f2, *g["h"])
+    for a in range(10):
+        want = g["J"][a]
+        assert J[a].shape == want.shape
+        # fp64 arithmetic in reference order, one rounding to fp32 storage
+        assert np.array_equal(J[a], want.astype(np.float32).astype(np.float64))
+
+
+# ---- K4-K7 solver -------------------------------------------------------------------------------------
+def _solve(hip, g, J, wt, it, lag, ad, fp64):
+    hx, hy, hz = g["h"]
+    return hip.level_solver(*list(J), wt, g["u"], g["v"], g["w"], (0.25, 0.3, 0.35), it, lag, 0,
+                            np.array(ad), 1.0, hx, hy, hz, solver_fp64=fp64)
+
+
+@pytest.mark.parametrize("fp64", [False, True])
+@pytest.mark.parametrize("case,it,lag,ad", [("c1_a045_s1", 12, 5, [0.45]), ("c1_a1_s1", 7, 3, [1.0]),
+                                            ("c2_a045_s1", 10, 5, [0.45, 0.6])])
+def test_level_solver_vs_reference_golden(hip, case, it, lag, ad, fp64):
+    g = golden("k7_solver")
+    tag = "c1" if case.startswith("c1") else "c2"
+    du, dv, dw = _solve(hip, g, g["J_" + tag], g["wt_" + tag], it, lag, ad, fp64)
+    want = g[case]
+    inner = (slice(1, -1),) * 3
+    err = max(np.abs(d[inner] - want[..., k][inner]).max() for k, d in enumerate((du, dv, dw)))
+    scale = np.abs(want).max()
+    # lexicographic-exact ordering; differences are fp32 storage / arithmetic only
+    assert err < (2e-5 if fp64 else 5e-5) * max(scale, 1.0), err
+
+
+def test_level_solver_matches_oracle_bigger(hip, oracle):
+    # a larger level, 40 iterations: wavefront pipelining of many in-flight iterations
+    from flowreg3d_amd.synthetic import make_pair
+    f1, f2, _ = make_pair((20, 30, 34), seed=11, scale=0.3)
+    hz = hy = hx = 1.0
+    J = oracle.get_motion_tensor_gc(f1, f2, hz, hy, hx)
+    J4 = [j[..., None] for j in J]
+    wt = np.pad(np.ones((20, 30, 34, 1)), ((1, 1), (1, 1), (1, 1), (0, 0)))
+    z = np.zeros((22, 32, 36))
+    want = oracle.compute_flow_3d(*J4, wt, z, z, z, 0.25, 0.25, 0.25, 40, 5, np.array([0.45]), 1.0, hx, hy, hz)
+    du, dv, dw = hip.level_solver(*J4, wt, z, z, z, (0.25, 0.25, 0.25), 40, 5, 0, np.array([0.45]), 1.0,
+                                  hx, hy, hz)
+    inner = (slice(1, -1),) * 3
+    got = np.stack([du[inner], dv[inner], dw[inner]], -1)
+    epe = np.linalg.norm(got - want[inner], axis=-1)
+    assert epe.mean() < 2e-5 and epe.max() < 2e-3, (epe.mean(), epe.max())
+
+
+# ---- K8 median ---------------------------------------------------------------------------------------
+def test_median_vs_reference_golden(hip):
+    g = golden("k8_median")
+    for k in ("a", "b"):
+        x = g[k].astype(np.float32)
+        got = hip.median_filter5(x)
+        # the fp32 cast is monotone, so the median of the casts is the cast of the median
+        assert np.array_equal(got, g[k + "_med"].astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(6, 6, 6), (7, 33, 65), (12, 9, 130)])
+def test_median_bit_exact_vs_oracle(hip, oracle, shape):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(shape).astype(np.float32)
+    x[1, 2, 3] = x[2, 2, 2]  # ties
+    assert np.array_equal(hip.median_filter5(x), oracle.median5(x).astype(np.float32))
