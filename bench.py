@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: volumes/sec of (3-D flow solve + final warp) on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg1]
+
+One "step" = one volume of a synthetic time series registered against a fixed reference:
+get_displacement (5-level pyramid at 256^3) + cubic compensation warp, i.e. one iteration of the
+executor body (flowreg3d motion_correction/parallelization/sequential_3d.py:148-160), through the
+C ABI entry fr3d_process_batch_dev with every input already resident in HBM.  With N > 1 (launched
+by torch.distributed.run, one rank per GPU) the series is sharded volume-per-GPU, the fixed
+reference is broadcast once from rank 0 over RCCL and nothing else is exchanged ("scaling": weak).
+
+Prints ONE JSON line on rank 0 (schema in the task contract) with `roofline` for the SOR sweep
+kernel (HIP events on the engine's stream) and `cpu_baseline` (the C oracle on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (Z, Y, X, levels, description)      "N-level pyramid" => levels = N-1, min_level = 0
+    "cfg1": (32, 64, 64, 2, "64x64x32 pair, 3-level pyramid"),
+    "cfg2": (256, 256, 256, 4, "256^3 single-channel fp32, 5-level pyramid"),
+    "cfg3": (512, 512, 512, 5, "512^3 single-channel fp32, 6-level pyramid"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def solver_kwargs(levels):
+    return dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=100, min_level=0, levels=levels,
+                eta=0.8, a_smooth=1.0, a_data=0.45)
+
+
+class DevArray:
+    """A float32 device buffer owned through the engine's allocator."""
+
+    def __init__(self, lib, shape):
+        self.lib, self.shape = lib, tuple(shape)
+        self.nbytes = int(np.prod(shape)) * 4
+        self.ptr = lib.fr3d_dev_malloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("fr3d_dev_malloc failed")
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.nbytes == self.nbytes
+        rc = self.lib.fr3d_h2d(self.ptr, a.ctypes.data, self.nbytes)
+        assert rc == 0
+        return self
+
+    def download(self):
+        out = np.empty(self.shape, np.float32)
+        rc = self.lib.fr3d_d2h(out.ctypes.data, self.ptr, self.nbytes)
+        assert rc == 0
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.lib.fr3d_dev_free(self.ptr)
+            self.ptr = None
+
+
+def cpu_baseline(workload, sample_edge):
+    """Time the CPU oracle (restatement of the reference's NumPy/Numba path) on one core on a
+    bounded cube of the same workload; scale to the workload's voxel count."""
+    from oracle import oracle
+    from flowreg3d_amd.synthetic import make_pair
+    Z, Y, X, levels, _ = WORKLOADS[workload]
+    e = min(sample_edge, Z, Y, X)
+    shape = (e, e, e) if workload != "cfg1" else (Z, Y, X)
+    fixed, moving, _ = make_pair(shape, seed=1234, cheap=True)
+    kw = solver_kwargs(levels)
+    t0 = time.perf_counter()
+    flow = oracle.get_displacement(fixed, moving, **kw).astype(np.float32)
+    oracle.imregister_wrapper(moving, flow[..., 0], flow[..., 1], flow[..., 2], fixed)
+    dt = time.perf_counter() - t0
+    scale = (shape[0] * shape[1] * shape[2]) / float(Z * Y * X)
+    return {"value": scale / dt, "unit": "volumes/sec", "cores": 1, "kind": "port",
+            "sample": f"{shape[0]}x{shape[1]}x{shape[2]} pair, same pyramid/solver parameters, "
+                      f"{dt:.1f} s on 1 core; scaled by voxel count to {Z}x{Y}x{X}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=80, help="edge of the CPU-baseline cube")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solver-fp64", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from flowreg3d_amd import _lib
+    from flowreg3d_amd.synthetic import flow_gt, texture
+    lib = _lib.init(local_rank)
+
+    Z, Y, X, levels, desc = WORKLOADS[args.workload]
+    nv = Z * Y * X
+    K, W = args.steps, args.warmup
+    T = K + W
+    kw = solver_kwargs(levels)
+    params = _lib.make_params(n_channels=1, solver_fp64=args.solver_fp64, **kw)
+
+    # ---- fixed reference: generated on rank 0, broadcast over RCCL/xGMI -----------------------
+    ref_dev = DevArray(lib, (Z, Y, X, 1))
+    if world > 1:
+        import torch
+        ref_t = torch.empty((Z, Y, X), dtype=torch.float32, device=f"cuda:{local_rank}")
+        if rank == 0:
+            ref_t.copy_(torch.from_numpy(texture((Z, Y, X), seed=1234)))
+        dist.broadcast(ref_t, src=0)  # the path's only collective
+        torch.cuda.synchronize()
+        fixed_ptr = ref_t.data_ptr()
+    else:
+        ref_dev.upload(texture((Z, Y, X), seed=1234))
+        fixed_ptr = ref_dev.ptr
+
+    # ---- this rank's shard of the time series: moving_t = warp(fixed, -flow_gt * s_t) on the GPU --
+    batch = DevArray(lib, (T, Z, Y, X, 1))
+    flows = DevArray(lib, (T, Z, Y, X, 3))
+    regs = DevArray(lib, (T, Z, Y, X, 1))
+    gflow = DevArray(lib, (Z, Y, X, 3))
+    for i in range(T):
+        t_global = rank + world * i
+        s = np.sin(2.0 * np.pi * (t_global + 1) / 64.0) + 0.35
+        gflow.upload(-flow_gt((Z, Y, X), scale=float(s)))
+        _lib.check(lib.fr3d_warp_dev(fixed_ptr, _lib.F32, gflow.ptr, _lib.F32, fixed_ptr, Z, Y, X, 1, 3,
+                                     batch.ptr + i * nv * 4))
+    gflow.free()
+
+    def run(first, count, prof):
+        lib.fr3d_prof_enable(1 if prof else 0)
+        if prof:
+            lib.fr3d_prof_reset()
+        _lib.check(lib.fr3d_process_batch_dev(
+            C.byref(params), batch.ptr + first * nv * 4, batch.ptr + first * nv * 4, fixed_ptr, fixed_ptr,
+            None, None, count, Z, Y, X, 1, 3, flows.ptr + first * nv * 12, regs.ptr + first * nv * 4,
+            C.cast(None, _lib.PROGRESS_FN), None))
+
+    def barrier():
+        lib.fr3d_sync()
+        if world > 1:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    if W > 0:
+        run(0, W, False)
+    barrier()
+    t0 = time.perf_counter()
+    run(W, K, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = _lib.prof_get()
+    lib.fr3d_prof_enable(0)
+    if world > 1:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        sor = stats["sor"]
+        achieved = sor["algo_bytes"] / (sor["ms"] * 1e-3) / 1e9 if sor["ms"] > 0 else 0.0
+        out = {
+            "metric": "volumes/sec (3D flow solve + warp)",
+            "value": (K * world) / elapsed,
+            "unit": "volumes/sec",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}; iterations=100, update_lag=5, eta=0.8, "
+                                   "alpha=0.25, a_data=0.45, a_smooth=1; lexicographic-exact SOR",
+                       "volumes_per_gpu_per_step": 1, "sharding": f"volume-per-GPU x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_sor_step (SOR hyperplane sweep)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algo_bytes_per_launch": sor["algo_bytes"] / max(sor["launches"], 1),
+                         "avg_launch_us": 1e3 * sor["ms"] / max(sor["launches"], 1),
+                         "launches": sor["launches"]},
+            "kernel_ms_per_step": {k: round(v["ms"] / K, 3) for k, v in stats.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,6 +79,33 @@ static int reflect_index(int j, int n)
     return j;
 }
 
+// np.exp on float32 as NumPy computes it on AVX2/AVX512 hosts (Cody-Waite + P5/Q2 rational, fp32
+// FMAs; numpy/_core/src/umath/loops_exponent_log.dispatch.c.src) -- the Gaussian taps of the
+// reference go through it (util/resize_util_3D.py:106) and libm's expf is 1 ulp off often enough to
+// matter at the 1e-5 flow level.
+static float numpy_expf(float x)
+{
+    const float log2e = 0x1.715476p+0f, magic = 0x1.800000p+23f;
+    const float c1 = -0x1.62e400p-1f, c2 = -0x1.7f7d1cp-20f;
+    const float P0 = 9.999999999980870924916e-01f, P1 = 7.257664613233124478488e-01f,
+                P2 = 2.473615434895520810817e-01f, P3 = 5.114512081637298353406e-02f,
+                P4 = 6.757896990527504603057e-03f, P5 = 5.082762527590693718096e-04f;
+    const float Q0 = 1.0f, Q1 = -2.742335390411667452936e-01f, Q2 = 2.159509375685829852307e-02f;
+    if (x < -87.0f) return 0.0f;
+    float q = x * log2e;
+    q = (q + magic) - magic;
+    float r = std::fmaf(q, c1, x);
+    r = std::fmaf(q, c2, r);
+    float num = std::fmaf(P5, r, P4);
+    num = std::fmaf(num, r, P3);
+    num = std::fmaf(num, r, P2);
+    num = std::fmaf(num, r, P1);
+    num = std::fmaf(num, r, P0);
+    float den = std::fmaf(Q2, r, Q1);
+    den = std::fmaf(den, r, Q0);
+    return std::ldexp(num / den, (int)q);
+}
+
 static float pairwise_sum(const std::vector<float> &a)
 {
     const int n = (int)a.size();
@@ -114,7 +141,7 @@ static HostTable build_table(int in_len, int out_len, double sigma)
         const float sig = (float)sigma;
         for (int k = 0; k < 2 * R + 1; k++) {
             float q = (float)(k - R) / sig;
-            g[k] = expf(-0.5f * (q * q));
+            g[k] = numpy_expf(-0.5f * (q * q));
         }
         float s = pairwise_sum(g);
         for (auto &v : g) v = v / s;

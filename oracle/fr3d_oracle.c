@@ -46,6 +46,35 @@ static int reflect_idx(int j, int n)
     return j;
 }
 
+/* NumPy's float32 np.exp as dispatched on AVX2/AVX512 x86 hosts (numpy/_core/src/umath/
+ * loops_exponent_log.dispatch.c.src, NumPy 2.2): Cody-Waite reduction + P5/Q2 rational
+ * minimax, all in fp32 with FMAs.  The Gaussian taps of the resampler go through it
+ * (util/resize_util_3D.py:106), and libm's expf differs from it by 1 ulp often enough to move
+ * the end-to-end flow by ~1e-5, so the restatement follows NumPy here.  Verified bit-identical
+ * to np.exp on 2e6 random float32 inputs in [-20, 0] (tools/gen_golden.py environment). */
+static float np_expf(float x)
+{
+    const float log2e = 0x1.715476p+0f, magic = 0x1.800000p+23f;
+    const float c1 = -0x1.62e400p-1f, c2 = -0x1.7f7d1cp-20f;
+    const float P0 = 9.999999999980870924916e-01f, P1 = 7.257664613233124478488e-01f,
+                P2 = 2.473615434895520810817e-01f, P3 = 5.114512081637298353406e-02f,
+                P4 = 6.757896990527504603057e-03f, P5 = 5.082762527590693718096e-04f;
+    const float Q0 = 1.0f, Q1 = -2.742335390411667452936e-01f, Q2 = 2.159509375685829852307e-02f;
+    if (x < -87.0f) return 0.0f; /* far below any tap the resampler evaluates */
+    float q = x * log2e;
+    q = (q + magic) - magic;
+    float r = fmaf(q, c1, x);
+    r = fmaf(q, c2, r);
+    float num = fmaf(P5, r, P4);
+    num = fmaf(num, r, P3);
+    num = fmaf(num, r, P2);
+    num = fmaf(num, r, P1);
+    num = fmaf(num, r, P0);
+    float den = fmaf(Q2, r, Q1);
+    den = fmaf(den, r, Q0);
+    return ldexpf(num / den, (int)q);
+}
+
 /* numpy's float32 pairwise add.reduce for n <= 128 (loops_utils.h.src: pairwise_sum) */
 static float np_sum_f32(const float *a, int n)
 {
@@ -83,7 +112,7 @@ int fr3d_oracle_resize_tables(int in_len, int out_len, double sigma, int *idx, f
             float x = (float)(k - R);
             float q = x / sig32;
             float e = -0.5f * (q * q);
-            g[k] = expf(e);
+            g[k] = np_expf(e);
         }
         float s = np_sum_f32(g, n);
         for (int k = 0; k < n; k++) g[k] = g[k] / s;
