@@ -1,0 +1,172 @@
+"""``HipExecutor3D`` -- the drop-in executor behind flowreg3d's parallelization plugin interface.
+
+Contract mirrored (all under /root/reference/src/flowreg3d/motion_correction/):
+  * ``BaseExecutor3D`` (parallelization/base_3d.py:11-120): ``__init__(n_workers)``, ``name``,
+    ``process_batch(batch, batch_proc, reference_raw, reference_proc, w_init, get_displacement_func,
+    imregister_func, interpolation_method="cubic", progress_callback=None, **kwargs)``
+    -> ``(registered (T,Z,Y,X,C) batch.dtype, flow_fields (T,Z,Y,X,3) float32)``, ``setup``,
+    ``cleanup``, ``get_info``, context manager, classmethod ``register()``.
+  * per-volume body of ``SequentialExecutor3D.process_batch`` (parallelization/sequential_3d.py:
+    148-175) -- executed for the whole batch by one C-ABI call, ``fr3d_process_batch``.
+  * registry: ``RuntimeContext.register_parallelization_executor(name, cls)`` (_runtime.py:149) with
+    name = class name minus "Executor", lower-cased (base_3d.py:97-104) -> ``"hip3d"``; selected by
+    ``RegistrationConfig(parallelization="hip")`` (compensate_recording_3D.py:88-94).
+
+When flowreg3d is importable the class registers into its real ``RuntimeContext``; otherwise into the
+minimal registry below (same two methods) so the package works standalone on the GPU box.  The two
+injected callables are ignored (precedent: MultiprocessingExecutor3D, multiprocessing_3d.py:269-270).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+from importlib import import_module
+from typing import Any, Callable, Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .core import _order_of, expand_weight
+
+
+class _LocalRuntimeContext:
+    """The two registry methods of flowreg3d._runtime.RuntimeContext (:149-199), dotted-path
+    storage included, for use when flowreg3d itself is not installed."""
+    _config: Dict[str, Any] = {"parallelization_registry": {}, "available_parallelization": set(),
+                               "max_workers": 1}
+
+    @classmethod
+    def get(cls, key, default=None):
+        return cls._config.get(key, default)
+
+    @classmethod
+    def register_parallelization_executor(cls, name, executor_class):
+        if isinstance(executor_class, type):
+            dotted = f"{executor_class.__module__}.{executor_class.__qualname__}"
+        else:
+            dotted = executor_class
+        cls._config["parallelization_registry"][name] = dotted
+        cls._config["available_parallelization"].add(name)
+
+    @classmethod
+    def get_parallelization_executor(cls, name=None):
+        if name is None:
+            return None
+        dotted = cls._config["parallelization_registry"].get(name)
+        if dotted is None:
+            return None
+        try:
+            mod, attr = dotted.rsplit(".", 1)
+            return getattr(import_module(mod), attr)
+        except (ImportError, AttributeError, ValueError) as e:
+            warnings.warn(f"Failed to import executor {name} from {dotted}: {e}")
+            return None
+
+
+def runtime_context():
+    """flowreg3d's RuntimeContext when importable, else the local stand-in."""
+    try:
+        from flowreg3d._runtime import RuntimeContext  # type: ignore
+        return RuntimeContext
+    except Exception:
+        return _LocalRuntimeContext
+
+
+class HipExecutor3D:
+    """Runs the per-volume flow solve + compensation warp of a batch on one MI355X."""
+
+    def __init__(self, n_workers: Optional[int] = None, device: Optional[int] = None):
+        self.n_workers = 1  # one process drives one GPU; volumes are pipelined on its stream
+        self.name = self.__class__.__name__.replace("Executor", "").lower()
+        self.device = device
+        self._lib = None
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def setup(self):
+        self._lib = _lib.init(self.device)
+
+    def cleanup(self):
+        pass  # the engine's workspace is kept for the next batch (same sizes every call)
+
+    def __enter__(self):
+        self.setup()
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.cleanup()
+        return False
+
+    @classmethod
+    def register(cls) -> bool:
+        """Register as ``hip3d``.  Declines (returns False) when no GPU / library is usable so the
+        pipeline's fallback chain (compensate_recording_3D.py:95-118) picks ``sequential3d``."""
+        if _lib.device_count() < 1:
+            return False
+        instance_name = cls.__name__.replace("Executor", "").lower()
+        runtime_context().register_parallelization_executor(instance_name, cls)
+        return True
+
+    def get_info(self) -> Dict[str, Any]:
+        return {"name": self.name, "type": self.__class__.__name__, "n_workers": self.n_workers,
+                "parallel": False, "backend": "hip/gfx950", "library": _lib.LIB_PATH,
+                "description": "MI355X engine: HIP pyramid, B-spline warp, SOR solver, median"}
+
+    # -- the plugin entry point ----------------------------------------------------------------
+    def process_batch(self, batch: np.ndarray, batch_proc: np.ndarray, reference_raw: np.ndarray,
+                      reference_proc: np.ndarray, w_init: np.ndarray,
+                      get_displacement_func: Callable = None, imregister_func: Callable = None,
+                      interpolation_method: str = "cubic",
+                      progress_callback: Optional[Callable[[int], None]] = None,
+                      **kwargs) -> Tuple[np.ndarray, np.ndarray]:
+        T, Z, Y, X, nc = batch.shape
+        order = _order_of(interpolation_method)
+        flow_params_all = dict(kwargs.get("flow_params", {}))
+        if flow_params_all.get("cc_initialization", False):
+            raise NotImplementedError("cross-correlation pre-alignment is not on the device path "
+                                      "(never enabled by the pipeline: compensate_recording_3D.py:301-315)")
+        fp = {k: v for k, v in flow_params_all.items() if k not in ("cc_initialization", "cc_hw", "cc_up")}
+        # get_displacement's own defaults (core/optical_flow_3d.py:319-333) for missing keys
+        alpha = fp.get("alpha", (2, 2, 2))
+        a_smooth = float(fp.get("a_smooth", 0.5))
+        if a_smooth != 1.0:
+            raise NotImplementedError("a_smooth != 1.0 is not implemented on the device yet")
+        params = _lib.make_params(alpha, fp.get("update_lag", 10), fp.get("iterations", 20),
+                                  fp.get("min_level", 0), fp.get("levels", 50), fp.get("eta", 0.8), a_smooth,
+                                  fp.get("a_data", 0.45), nc, bool(fp.get("solver_fp64", False)))
+        wt = expand_weight(fp.get("weight", None), Z, Y, X, nc)
+
+        def f32(a, shape):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.shape != shape:
+                raise ValueError(f"array has shape {a.shape}, expected {shape}")
+            return a
+
+        bp = f32(batch_proc, (T, Z, Y, X, nc))
+        br = f32(batch, (T, Z, Y, X, nc))
+        rp = f32(np.asarray(reference_proc).reshape(Z, Y, X, nc), (Z, Y, X, nc))
+        rr = f32(np.asarray(reference_raw).reshape(Z, Y, X, nc), (Z, Y, X, nc))
+        wi = None if w_init is None else f32(w_init, (Z, Y, X, 3))
+        w32 = None if wt is None else f32(wt, (Z, Y, X, nc))
+        flows = np.empty((T, Z, Y, X, 3), np.float32)
+        reg32 = np.empty((T, Z, Y, X, nc), np.float32)
+
+        cb_error = []
+
+        def _progress(n, _user):
+            if progress_callback is not None:
+                try:
+                    progress_callback(int(n))
+                except Exception as e:  # never unwind through the C frame
+                    cb_error.append(e)
+
+        cb = _lib.PROGRESS_FN(_progress)
+        lib = self._lib or _lib.init(self.device)
+        _lib.check(lib.fr3d_process_batch(C.byref(params), _lib.ptr(bp), _lib.ptr(br), _lib.ptr(rp), _lib.ptr(rr),
+                                          _lib.ptr(wi), _lib.ptr(w32), T, Z, Y, X, nc, order, _lib.ptr(flows),
+                                          _lib.ptr(reg32), cb, None))
+        if cb_error:
+            raise cb_error[0]
+        # registered[t] = reg_volume stores fp32 into an array of batch.dtype (sequential_3d.py:75,163-170)
+        registered = np.empty_like(batch)
+        registered[...] = reg32
+        return registered, flows

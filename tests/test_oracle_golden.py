@@ -1,0 +1,102 @@
+"""CPU: the oracle (oracle/fr3d_oracle.c) pinned against outputs of the reference itself
+(tests/golden/*.npz, produced by tools/gen_golden.py from /root/reference).  Stage fixtures are
+reproduced bit for bit where the arithmetic is reference-owned; SciPy's spline prefilter to 1e-14."""
+import numpy as np
+import pytest
+
+from conftest import golden, params_of
+
+
+def test_resize_tables_bit_exact(oracle):
+    g = golden("k1_resize")
+    for k, (a, b, s) in enumerate(g["table_cases"]):
+        idx, wt = oracle.resize_tables(int(a), int(b), float(s))
+        assert np.array_equal(idx, g[f"idx{k}"])
+        assert np.array_equal(wt, g[f"wt{k}"])
+
+
+def test_resize3d_bit_exact(oracle):
+    g = golden("k1_resize")
+    for name, size in (("down", (11, 15, 17)), ("up", (23, 28, 33)), ("mixed", (18, 30, 13))):
+        got = oracle.imresize_fused_gauss_cubic3D(g["vol"], size)
+        assert got.dtype == g[name].dtype and np.array_equal(got, g[name])
+    got = oracle.imresize_fused_gauss_cubic3D(g["vol4"], (12, 14, 20))
+    assert got.dtype == np.float64 and np.array_equal(got, g["down4"])
+
+
+def test_spline_prefilter_matches_scipy(oracle):
+    g = golden("k2_warp")
+    c = oracle.spline_filter3(np.pad(g["spline_in"], 12, mode="edge"))
+    assert np.abs(c - g["spline_coef"]).max() < 1e-14
+    # short lines exercise SciPy's in-place initialisation quirk
+    from scipy.ndimage import spline_filter
+    rng = np.random.default_rng(0)
+    for shape in ((2, 3, 5), (9, 11, 13), (4, 30, 7)):
+        a = rng.random(shape)
+        assert np.abs(oracle.spline_filter3(a) - spline_filter(a, 3, output=np.float64, mode="nearest")).max() < 1e-13
+
+
+@pytest.mark.parametrize("method", ["cubic", "linear"])
+def test_imregister_bit_exact(oracle, method):
+    g = golden("k2_warp")
+    got = oracle.imregister_wrapper(g["f2"], g["u"], g["v"], g["w"], g["f1"], method)
+    assert got.dtype == np.float32 and np.array_equal(got, g[method])
+
+
+def test_imregister_single_channel_and_errors(oracle):
+    g = golden("k2_warp")
+    got = oracle.imregister_wrapper(g["f2"][..., 0], g["u"], g["v"], g["w"], g["f1"][..., 0])
+    assert got.shape == g["cubic_c1"].shape and np.array_equal(got, g["cubic_c1"])
+    with pytest.raises(ValueError):
+        oracle.imregister_wrapper(g["f2"], g["u"], g["v"], g["w"], g["f1"], "nearest")
+
+
+def test_motion_tensor_bit_exact(oracle):
+    g = golden("k3_tensor")
+    J = oracle.get_motion_tensor_gc(g["f1"], g["f2"], *g["h"])
+    for a in range(10):
+        assert np.array_equal(J[a], g["J"][a])
+
+
+@pytest.mark.parametrize("case,tag,it,lag,ad,asm", [
+    ("c1_a045_s1", "c1", 12, 5, [0.45], 1.0), ("c1_a1_s1", "c1", 7, 3, [1.0], 1.0),
+    ("c1_a045_s05", "c1", 6, 2, [0.45], 0.5), ("c2_a045_s1", "c2", 10, 5, [0.45, 0.6], 1.0)])
+def test_compute_flow_3d_bit_exact(oracle, case, tag, it, lag, ad, asm):
+    g = golden("k7_solver")
+    hx, hy, hz = g["h"]
+    got = oracle.compute_flow_3d(*list(g["J_" + tag]), g["wt_" + tag], g["u"], g["v"], g["w"], 0.25, 0.3, 0.35,
+                                 it, lag, np.array(ad), asm, hx, hy, hz)
+    assert np.array_equal(got, g[case])
+
+
+def test_median_bit_exact(oracle):
+    g = golden("k8_median")
+    assert np.array_equal(oracle.median5(g["a"]), g["a_med"])
+    assert np.array_equal(oracle.median5(g["b"]), g["b_med"])
+
+
+def test_schedule(oracle):
+    g = golden("schedule")
+    for p, m, n, eta, levels, depth in g["rows"]:
+        assert oracle.warpingDepth(eta, int(levels), int(p), int(m), int(n)) == int(depth)
+    sizes, eff = oracle.schedule(512, 512, 512, 0.8, 5, 0)
+    assert sizes == [(168,) * 3, (210,) * 3, (262,) * 3, (328,) * 3, (410,) * 3, (512,) * 3] and eff == 0
+    sizes, eff = oracle.schedule(32, 64, 64, 0.8, 2, 0)
+    assert sizes == [(20, 41, 41), (26, 51, 51), (32, 64, 64)]
+    sizes, eff = oracle.schedule(256, 512, 512, 0.8, 100, 5)
+    assert sizes[0] == (9, 18, 18) and sizes[-1] == (84, 168, 168) and len(sizes) == 11
+
+
+@pytest.mark.parametrize("name,tol_mean,tol_max", [
+    ("e2e_small", 2e-6, 5e-5), ("e2e_asmooth", 1e-7, 1e-6), ("e2e_c2", 4e-6, 1e-4),
+    ("e2e_minlevel", 2e-6, 1e-4), ("e2e_cfg1", 8e-6, 1e-3)])
+def test_get_displacement_vs_reference(oracle, name, tol_mean, tol_max):
+    """Whole pipeline.  Every stage above is bit-exact except SciPy's prefilter (1e-15 relative);
+    an fp32 rounding of a warped voxel that flips on that moves the flow by ~1e-6, hence a
+    tolerance rather than equality here."""
+    g = golden(name)
+    flow = oracle.get_displacement(g["fixed"], g["moving"], uvw=g["uvw"] if "uvw" in g else None,
+                                   weight=g["weight"] if "weight" in g else None, **params_of(g))
+    assert flow.shape == g["flow"].shape and flow.dtype == np.float64
+    d = np.linalg.norm(flow - g["flow"], axis=-1)
+    assert d.mean() < tol_mean and d.max() < tol_max, (d.mean(), d.max())
