@@ -4,6 +4,7 @@
 // include/flowreg3d_hip.h.  Everything between the entry copy-in and the exit copy-out stays in
 // HBM; the only host work per level is the (cached) table build and kernel launches.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -210,6 +211,15 @@ struct Engine {
     hipStream_t st = nullptr;
     std::map<std::string, DevBuf> bufs;
     std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
+    std::map<std::tuple<int, int, int, int>, SorSched> scheds;     // (Z,Y,X,iterations) of a level
+
+    const SorSched &sched(const Skew &sk, int iterations)
+    {
+        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations);
+        auto it = scheds.find(key);
+        if (it == scheds.end()) it = scheds.emplace(key, build_sor_schedule(sk, iterations)).first;
+        return it->second;
+    }
     // profiling
     bool prof = false;
     std::vector<ProfSpan> spans;
@@ -371,14 +381,19 @@ static void build_ref_pyramid(Engine &e, const std::vector<Level> &lv, const flo
     }
 }
 
+// Solve `nb` volumes against the same reference pyramid in lock step: every stage before and after
+// the solver runs per volume, the SOR launches advance all nb volumes at once (the launch count per
+// level is fixed by the wavefront schedule, so batching multiplies the work per launch and hides
+// the pipeline fill/drain launches that are too small to occupy the chip).
 static void get_displacement_core(Engine &e, const fr3d_params &p, const std::vector<Level> &lv,
-                                  int min_level, const RefPyramid &rp, const float *moving,
-                                  int Z, int Y, int X, int C, const float *uvw_init, float *flow_out)
+                                  int min_level, const RefPyramid &rp, int nb, const float *const *moving,
+                                  int Z, int Y, int X, int C, const float *uvw_init, float *const *flow_out,
+                                  int reserve_nb = 1)
 {
     FR3D_CHECK(p.a_smooth == 1.0, "a_smooth != 1 is not implemented on the device (SURVEY 8f-3)");
+    FR3D_CHECK(nb >= 1 && nb <= 64, "internal: bad batch size");
     const size_t nfull = (size_t)Z * Y * X;
-    float *uvw[3] = {nullptr, nullptr, nullptr};
-    float *uvw_prev[3];
+    std::vector<float *> uvw(3 * nb, nullptr), uvw_prev(3 * nb, nullptr);
     int pz = 0, py = 0, px = 0;
     int flip = 0;
 
@@ -388,118 +403,162 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
         const size_t nl = (size_t)lz * ly * lx;
         const double hz = (double)Z / lz, hy = (double)Y / ly, hx = (double)X / lx;
         const float *f1l = rp.f1[li];
-        float *f2l = e.f32("f2l", nl * C);
-        for (int c = 0; c < C; c++) resize3d(e, moving, C, c, Z, Y, X, lz, ly, lx, f2l + (size_t)c * nl);
 
-        // level flow (interior; ghosts are the edge pad of :88-89, implied)
-        for (int d = 0; d < 3; d++) uvw_prev[d] = uvw[d];
-        const std::string sfx = flip ? "_a" : "_b";
-        flip ^= 1;
-        for (int d = 0; d < 3; d++) uvw[d] = e.f32(std::string("uvw") + char('0' + d) + sfx, nl);
-        const float *warped = f2l;
-        if (li == 0) {
-            for (int d = 0; d < 3; d++) {
-                if (uvw_init) resize3d(e, uvw_init, 3, d, Z, Y, X, lz, ly, lx, uvw[d]);
-                else launch_fill(e.st, uvw[d], 0.0f, (long long)nl);
-            }
-        } else {
-            for (int d = 0; d < 3; d++) resize3d(e, uvw_prev[d], 1, 0, pz, py, px, lz, ly, lx, uvw[d]);
-            float *wbuf = e.f32("warped", nl * C);
-            for (int c = 0; c < C; c++)
-                warp_cubic_chan<float, float>(e, f2l + (size_t)c * nl, 1, 0, uvw[0], uvw[1], uvw[2], 1,
-                                              hx, hy, hz, f1l + (size_t)c * nl, lz, ly, lx,
-                                              wbuf + (size_t)c * nl, 1, 0);
-            warped = wbuf;
-        }
-
-        // solver operands in the skewed layout
+        // solver operands in the skewed layout, one slab per volume of the batch
         const Skew sk = make_skew(lz, ly, lx);
         const size_t ns = (size_t)sk.total;
-        float *Jbuf = e.f32("J_sk", ns * 9 * C);
-        float *Abuf = e.f32("A_sk", ns * 12 * C);
+        const size_t nres = (size_t)std::max(nb, reserve_nb);  // slabs reserved (>= nb)
+        float *Jbuf = e.f32("J_sk", ns * 9 * C * nres);
+        float *Abuf = e.f32("A_sk", ns * 12 * C * nres);
         float *wsk = e.f32("w_sk", ns * C);
-        float *wpsi = e.f32("wpsi_sk", ns * C);
-        float *Lbuf = e.f32("L_sk", ns * 3);
-        float *dbuf = e.f32("d_sk", ns * 3);
+        float *wpsi = e.f32("wpsi_sk", ns * C * nres);
+        float *Lbuf = e.f32("L_sk", ns * 3 * nres);
+        float *dbuf = e.f32("d_sk", ns * 3 * nres);
         SorArgs a;
         std::memset(&a, 0, sizeof(a));
         a.sk = sk;
         a.C = C;
-        {
-            Span sp(e, FR3D_K_TENSOR, 4.0 * (2 + 21) * nl * C, C, (long long)nl * C);
-            for (int c = 0; c < C; c++) {
-                // reference order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 -> solver slots (J44 is
-                // not stored: psi comes from the factors)
-                float *base = Jbuf + (size_t)c * 9 * ns;
-                float *abase = Abuf + (size_t)c * 12 * ns;
-                float *Jo[10] = {base + 0 * ns, base + 1 * ns, base + 2 * ns, nullptr, base + 3 * ns,
-                                 base + 4 * ns, base + 5 * ns, base + 6 * ns, base + 7 * ns, base + 8 * ns};
-                launch_motion_tensor(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
-                                     hx, Jo, abase, (long long)ns, &sk);
-                for (int q = 0; q < 9; q++) a.J[q * FR3D_MAX_CHANNELS + c] = base + (size_t)q * ns;
-                for (int q = 0; q < 12; q++) a.A[q * FR3D_MAX_CHANNELS + c] = abase + (size_t)q * ns;
-                a.weight[c] = wsk + (size_t)c * ns;
-                a.wpsi[c] = wpsi + (size_t)c * ns;
-                a.a_data[c] = p.a_data[c];
-            }
+        a.nvol = nb;
+        a.vsJ = (long long)ns * 9 * C;
+        a.vsA = (long long)ns * 12 * C;
+        a.vsP = (long long)ns * C;
+        a.vsL = (long long)ns * 3;
+        a.vsD = (long long)ns * 3;
+        // alpha schedule (:485-490) and alpha/h^2 (level_solver_3d.py:473-475)
+        const double sc = (L.idx == min_level) ? 1.0 : std::pow(p.eta, -0.5 * (double)L.idx);
+        a.ax = (sc * p.alpha[0]) / (hx * hx);
+        a.ay = (sc * p.alpha[1]) / (hy * hy);
+        a.az = (sc * p.alpha[2]) / (hz * hz);
+        for (int c = 0; c < C; c++) {
+            for (int q = 0; q < 9; q++) a.J[q * FR3D_MAX_CHANNELS + c] = Jbuf + ((size_t)c * 9 + q) * ns;
+            for (int q = 0; q < 12; q++) a.A[q * FR3D_MAX_CHANNELS + c] = Abuf + ((size_t)c * 12 + q) * ns;
+            a.weight[c] = wsk + (size_t)c * ns;
+            a.wpsi[c] = wpsi + (size_t)c * ns;
+            a.a_data[c] = p.a_data[c];
+        }
+        for (int d = 0; d < 3; d++) {
+            a.L[d] = Lbuf + (size_t)d * ns;
+            a.d[d] = dbuf + (size_t)d * ns;
         }
         {
             Span sp(e, FR3D_K_OTHER, 0, 0, 0);
             for (int c = 0; c < C; c++) launch_skew_copy(e.st, rp.wl[li] + (size_t)c * nl, sk, wsk + (size_t)c * ns);
-            // alpha schedule (:485-490) and alpha/h^2 (level_solver_3d.py:473-475)
-            const double sc = (L.idx == min_level) ? 1.0 : std::pow(p.eta, -0.5 * (double)L.idx);
-            a.ax = (sc * p.alpha[0]) / (hx * hx);
-            a.ay = (sc * p.alpha[1]) / (hy * hy);
-            a.az = (sc * p.alpha[2]) / (hz * hz);
-            for (int d = 0; d < 3; d++) {
-                a.L[d] = Lbuf + (size_t)d * ns;
-                a.d[d] = dbuf + (size_t)d * ns;
+            FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(float), e.st));
+        }
+
+        const std::string sfx = flip ? "_a" : "_b";
+        flip ^= 1;
+        for (int b = nb; b < (int)nres; b++)  // reserved slots: allocate now, not inside a later timed batch
+            for (int d = 0; d < 3; d++) (void)e.f32(std::string("uvw") + char('0' + d) + sfx + std::to_string(b), nl);
+        for (int b = 0; b < nb; b++) {
+            float *f2l = e.f32("f2l", nl * C);
+            for (int c = 0; c < C; c++) resize3d(e, moving[b], C, c, Z, Y, X, lz, ly, lx, f2l + (size_t)c * nl);
+
+            // level flow (interior; ghosts are the edge pad of :88-89, implied)
+            float **u = &uvw[3 * b], **up = &uvw_prev[3 * b];
+            for (int d = 0; d < 3; d++) up[d] = u[d];
+            for (int d = 0; d < 3; d++)
+                u[d] = e.f32(std::string("uvw") + char('0' + d) + sfx + std::to_string(b), nl);
+            const float *warped = f2l;
+            if (li == 0) {
+                for (int d = 0; d < 3; d++) {
+                    if (uvw_init) resize3d(e, uvw_init, 3, d, Z, Y, X, lz, ly, lx, u[d]);
+                    else launch_fill(e.st, u[d], 0.0f, (long long)nl);
+                }
+            } else {
+                for (int d = 0; d < 3; d++) resize3d(e, up[d], 1, 0, pz, py, px, lz, ly, lx, u[d]);
+                float *wbuf = e.f32("warped", nl * C);
+                for (int c = 0; c < C; c++)
+                    warp_cubic_chan<float, float>(e, f2l + (size_t)c * nl, 1, 0, u[0], u[1], u[2], 1, hx, hy, hz,
+                                                  f1l + (size_t)c * nl, lz, ly, lx, wbuf + (size_t)c * nl, 1, 0);
+                warped = wbuf;
             }
-            launch_laplace(e.st, uvw[0], uvw[1], uvw[2], sk, a.ax, a.ay, a.az, Lbuf, Lbuf + ns, Lbuf + 2 * ns);
-            FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * sizeof(float), e.st));
+            {
+                Span sp(e, FR3D_K_TENSOR, 4.0 * (2 + 21) * nl * C, C, (long long)nl * C);
+                for (int c = 0; c < C; c++) {
+                    // reference order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 -> solver slots (J44 is
+                    // not stored: psi comes from the factors)
+                    float *base = Jbuf + (size_t)b * a.vsJ + (size_t)c * 9 * ns;
+                    float *abase = Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns;
+                    float *Jo[10] = {base + 0 * ns, base + 1 * ns, base + 2 * ns, nullptr, base + 3 * ns,
+                                     base + 4 * ns, base + 5 * ns, base + 6 * ns, base + 7 * ns, base + 8 * ns};
+                    launch_motion_tensor(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
+                                         hx, Jo, abase, (long long)ns, &sk);
+                }
+            }
+            {
+                Span sp(e, FR3D_K_OTHER, 0, 0, 0);
+                float *Lb = Lbuf + (size_t)b * a.vsL;
+                launch_laplace(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Lb, Lb + ns, Lb + 2 * ns);
+            }
         }
         a.iterations = p.iterations;
         a.update_lag = p.update_lag;
         {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
-            long long n = launch_sor(e.st, a, p.solver_fp64 != 0);
-            sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations, n, (long long)nl * p.iterations);
+            long long n = launch_sor(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
+            sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
         }
         // increments back to the natural layout, 5^3 median (:517-526), accumulate (:527-529)
-        float *dn = e.f32("d_nat", nl * 3);
-        float *dm = e.f32("d_med", nl * 3);
-        {
-            Span sp(e, FR3D_K_OTHER, 0, 0, 0);
-            for (int d = 0; d < 3; d++) launch_unskew_copy(e.st, dbuf + (size_t)d * ns, sk, dn + (size_t)d * nl);
-        }
         const bool med = std::min(lz, std::min(ly, lx)) > 5;
-        if (med) {
-            Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);
-            for (int d = 0; d < 3; d++) launch_median5(e.st, dn + (size_t)d * nl, lz, ly, lx, dm + (size_t)d * nl);
-        }
-        {
-            Span sp(e, FR3D_K_OTHER, 0, 0, 0);
-            for (int d = 0; d < 3; d++) launch_axpy(e.st, uvw[d], (med ? dm : dn) + (size_t)d * nl, (long long)nl);
+        for (int b = 0; b < nb; b++) {
+            float *dn = e.f32("d_nat", nl * 3);
+            float *dm = e.f32("d_med", nl * 3);
+            float **u = &uvw[3 * b];
+            {
+                Span sp(e, FR3D_K_OTHER, 0, 0, 0);
+                for (int d = 0; d < 3; d++)
+                    launch_unskew_copy(e.st, dbuf + (size_t)b * a.vsD + (size_t)d * ns, sk, dn + (size_t)d * nl);
+            }
+            if (med) {
+                Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);
+                for (int d = 0; d < 3; d++) launch_median5(e.st, dn + (size_t)d * nl, lz, ly, lx, dm + (size_t)d * nl);
+            }
+            {
+                Span sp(e, FR3D_K_OTHER, 0, 0, 0);
+                for (int d = 0; d < 3; d++) launch_axpy(e.st, u[d], (med ? dm : dn) + (size_t)d * nl, (long long)nl);
+            }
         }
         pz = lz; py = ly; px = lx;
     }
 
     // :530-541
-    {
-        const size_t nl = (size_t)pz * py * px;
+    const size_t nl = (size_t)pz * py * px;
+    for (int b = 0; b < nb; b++) {
+        float **u = &uvw[3 * b];
+        float *full = e.f32("flow_full", nfull * 3);
         if (min_level > 0) {
-            float *full = e.f32("flow_full", nfull * 3);
-            for (int d = 0; d < 3; d++) resize3d(e, uvw[d], 1, 0, pz, py, px, Z, Y, X, full + (size_t)d * nfull);
-            launch_pack(e.st, full, 3, (long long)nfull, flow_out);
+            for (int d = 0; d < 3; d++) resize3d(e, u[d], 1, 0, pz, py, px, Z, Y, X, full + (size_t)d * nfull);
         } else {
             FR3D_CHECK(nl == nfull, "internal: finest level is not full resolution");
-            float *tmp = e.f32("flow_full", nfull * 3);
             for (int d = 0; d < 3; d++)
-                FR3D_HIP(hipMemcpyAsync(tmp + (size_t)d * nfull, uvw[d], nfull * sizeof(float),
+                FR3D_HIP(hipMemcpyAsync(full + (size_t)d * nfull, u[d], nfull * sizeof(float),
                                         hipMemcpyDeviceToDevice, e.st));
-            launch_pack(e.st, tmp, 3, (long long)nfull, flow_out);
         }
+        launch_pack(e.st, full, 3, (long long)nfull, flow_out[b]);
     }
+}
+
+// How many volumes to solve in lock step: FR3D_BATCH (default 4), bounded by free HBM
+// (29 skewed operand arrays per volume and channel set).
+static int g_batch_hint = 0;  // fr3d_set_batch()
+
+static int pick_batch(int T, const std::vector<Level> &lv, int C)
+{
+    static const char *env = getenv("FR3D_BATCH");
+    int want = g_batch_hint > 0 ? g_batch_hint : (env ? std::max(1, atoi(env)) : 4);
+    if (want > T) want = T;
+    if (want < 1) want = 1;
+    const Level &F = lv.back();
+    const Skew sk = make_skew(F.z, F.y, F.x);
+    const double per_vol = (double)sk.total * 4.0 * (9.0 * C + 12.0 * C + C + 6.0);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        // buffers already held by the engine are reused, so this is conservative
+        const double budget = 0.85 * (double)total_b;
+        while (want > 1 && per_vol * want > budget) want--;
+    }
+    return want;
 }
 
 static void check_params(const fr3d_params *p, int Z, int Y, int X, int C)
@@ -524,7 +583,7 @@ static void get_displacement_dev(const fr3d_params *p, const float *fixed, const
     std::vector<Level> lv = make_schedule(Z, Y, X, p->eta, p->levels, min_level);
     RefPyramid rp;
     build_ref_pyramid(e, lv, fixed, weight, Z, Y, X, C, rp, "gd_");
-    get_displacement_core(e, *p, lv, min_level, rp, moving, Z, Y, X, C, uvw_init, flow_out);
+    get_displacement_core(e, *p, lv, min_level, rp, 1, &moving, Z, Y, X, C, uvw_init, &flow_out);
     FR3D_HIP(hipStreamSynchronize(e.st));
 }
 
@@ -581,15 +640,25 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     // the fixed-reference pyramid and the weight pyramid are time-invariant: build once
     build_ref_pyramid(e, lv, ref_proc, weight, Z, Y, X, C, rp, "pb_");
     const size_t nv = (size_t)Z * Y * X;
-    for (int t = 0; t < T; t++) {
-        float *flow = flows_out + (size_t)t * nv * 3;
-        get_displacement_core(e, *p, lv, min_level, rp, batch_proc + (size_t)t * nv * C, Z, Y, X, C, w_init,
-                              flow);
-        warp_dev_t<float, float>(batch_raw + (size_t)t * nv * C, flow, ref_raw, Z, Y, X, C, order,
-                                 registered_out + (size_t)t * nv * C);
+    const int B = T > 0 ? pick_batch(T, lv, C) : 1;
+    for (int t0 = 0; t0 < T; t0 += B) {
+        const int nb = std::min(B, T - t0);
+        std::vector<const float *> mov(nb);
+        std::vector<float *> fl(nb);
+        for (int b = 0; b < nb; b++) {
+            mov[b] = batch_proc + (size_t)(t0 + b) * nv * C;
+            fl[b] = flows_out + (size_t)(t0 + b) * nv * 3;
+        }
+        get_displacement_core(e, *p, lv, min_level, rp, nb, mov.data(), Z, Y, X, C, w_init, fl.data(),
+                              g_batch_hint > 0 ? pick_batch(g_batch_hint, lv, C) : B);
+        for (int b = 0; b < nb; b++) {
+            const int t = t0 + b;
+            warp_dev_t<float, float>(batch_raw + (size_t)t * nv * C, fl[b], ref_raw, Z, Y, X, C, order,
+                                     registered_out + (size_t)t * nv * C);
+        }
         if (progress) {
             FR3D_HIP(hipStreamSynchronize(e.st));
-            progress(1, user);
+            for (int b = 0; b < nb; b++) progress(1, user);
         }
     }
     FR3D_HIP(hipStreamSynchronize(e.st));
@@ -639,6 +708,12 @@ extern "C" {
 const char *fr3d_last_error(void) { return g_err.c_str(); }
 const char *fr3d_version(void) { return "flowreg3d_amd 0.1 (gfx950)"; }
 
+int fr3d_set_batch(int nvol)
+{
+    g_batch_hint = nvol > 0 ? nvol : 0;
+    return 0;
+}
+
 int fr3d_device_count(void)
 {
     int n = 0;
@@ -675,6 +750,8 @@ void fr3d_shutdown(void)
         (void)hipFree(kv.second.wt);
     }
     g_eng.tables.clear();
+    for (auto &kv : g_eng.scheds) free_sor_schedule(kv.second);
+    g_eng.scheds.clear();
     for (auto &s : g_eng.spans) {
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);
@@ -878,7 +955,7 @@ int fr3d_level_solve(const float *J, const float *A, const float *weight, const 
     FR3D_HIP(hipMemsetAsync(db, 0, ns * 3 * 4, e.st));
     a.iterations = iterations;
     a.update_lag = update_lag;
-    launch_sor(e.st, a, solver_fp64 != 0);
+    launch_sor(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
     for (int d = 0; d < 3; d++) launch_unskew_copy(e.st, db + (size_t)d * ns, sk, dn + (size_t)d * n);
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 4, hipMemcpyDeviceToHost));

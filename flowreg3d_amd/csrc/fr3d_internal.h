@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/flowreg3d_hip.h"
 
@@ -76,6 +77,11 @@ struct SorArgs {
     double a_data[FR3D_MAX_CHANNELS];
     int C;
     int iterations, update_lag;
+    // batch of volumes solved in lock step by the same launches: pointers above are volume 0,
+    // volume v adds v*stride elements (weights are shared by all volumes of a batch)
+    int nvol;
+    long long vsJ, vsA, vsP, vsL, vsD;
+    int dbg;  // measurement-only ablation bits (FR3D_SOR_DBG); 0 in production
 };
 
 // ---- launchers (each enqueues on `st`, no synchronisation) ------------------------------------
@@ -112,8 +118,22 @@ void launch_skew_copy(hipStream_t st, const float *src, const Skew &sk, float *d
 void launch_unskew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst);
 void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
                     double ax, double ay, double az, float *Lu, float *Lv, float *Lw);
+// Launch schedule of one level geometry: for every launch tau and every in-flight iteration t the
+// bounding box (in tile units) of the valid part of hyperplane s = tau - 2t, so that only tiles that
+// can hold voxels are dispatched (an all-covering grid spends ~8 us per launch on empty workgroups).
+struct SorEntry {
+    int pre;               // tiles of this launch before this iteration
+    short kb0, jb0, njb;   // first k-tile, first j-tile, j-tiles per k-tile row
+    short pad;
+};
+struct SorSched {
+    std::vector<int> tau, t_lo, nt, first, ntiles;  // per launch
+    SorEntry *entries = nullptr;                     // device, sum(nt) entries
+};
+SorSched build_sor_schedule(const Skew &sk, int iterations);
+void free_sor_schedule(SorSched &s);
 // Runs all `iterations` pipelined hyperplane steps.  Returns the number of kernel launches.
-long long launch_sor(hipStream_t st, const SorArgs &a, bool fp64);
+long long launch_sor(hipStream_t st, const SorArgs &a, bool fp64, const SorSched &sched);
 
 // K8 median (natural layout)
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);

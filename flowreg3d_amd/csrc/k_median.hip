@@ -1,11 +1,10 @@
 // k_median.hip -- K8: exact 5x5x5 median with mirror boundary
 // (scipy.ndimage.median_filter(size=(5,5,5), mode="mirror"), core/optical_flow_3d.py:517-526).
 //
-// Rank 62 of 125 by "forgetful selection": keep a register-resident working set that starts with
-// 64 samples; its minimum and maximum can never be the median, so both are dropped and one new
-// sample is taken in -- 61 rounds later three samples are left and their median is the answer.
-// All loops are fully unrolled so the working set stays in VGPRs (no scratch); compute-bound
-// (~4.1k compare-exchanges per voxel), exact for any input (no histogram / approximation).
+// Rank 62 of 125 by a selection network: the window is held in 128 VGPRs (3 slots padded with
+// +inf) and pushed through Batcher's odd-even merge sort with every index static, of which the
+// compiler keeps only the min/max operations that can reach output 62.  Compute-bound, exact for
+// any input (no histogram / approximation), no scratch.
 #include "fr3d_internal.h"
 
 namespace fr3d {
@@ -27,24 +26,35 @@ __device__ __forceinline__ int mirror(int i, int n)
     return i < n ? i : period - i;
 }
 
-template <int N>
-struct Round {
-    // working set a[0..N-1] -> drop min and max, take sample number (125 - (N - 3)) ... see caller
-    template <typename F>
-    static __device__ __forceinline__ void run(float (&a)[64], F &&next)
+// Batcher's odd-even merge sort on a register array, fully unrolled (all indices static).  Only
+// a[62] is read afterwards, so the compiler removes every min/max that cannot reach it: what is
+// left is a rank-62 selection network (~1.2k min/max pairs instead of the 4.1k compare-exchanges
+// of round-by-round forgetful selection).
+template <int LO, int N, int R>
+struct OEMerge {
+    static __device__ __forceinline__ void run(float (&a)[128])
     {
+        constexpr int M = R * 2;
+        if constexpr (M < N) {
+            OEMerge<LO, N, M>::run(a);
+            OEMerge<LO + R, N, M>::run(a);
 #pragma unroll
-        for (int q = 1; q < N; q++) cex(a[0], a[q]);
-#pragma unroll
-        for (int q = 1; q < N - 1; q++) cex(a[q], a[N - 1]);
-        a[0] = next(64 + (64 - N));
-        Round<N - 1>::run(a, next);
+            for (int i = LO + R; i + R < LO + N; i += M) cex(a[i], a[i + R]);
+        } else {
+            cex(a[LO], a[LO + R]);
+        }
     }
 };
-template <>
-struct Round<3> {
-    template <typename F>
-    static __device__ __forceinline__ void run(float (&)[64], F &&) {}
+template <int LO, int N>
+struct OESort {
+    static __device__ __forceinline__ void run(float (&a)[128])
+    {
+        if constexpr (N > 1) {
+            OESort<LO, N / 2>::run(a);
+            OESort<LO + N / 2, N / 2>::run(a);
+            OEMerge<LO, N, 1>::run(a);
+        }
+    }
 };
 
 __global__ void __launch_bounds__(256)
@@ -65,16 +75,12 @@ k_median5(const float *__restrict__ in, int Z, int Y, int X, float *__restrict__
         yo[q] = (long long)mirror(y + q - 2, Y) * X;
         xo[q] = mirror(x + q - 2, X);
     }
-    auto sample = [&](int n) -> float {  // n in 0..124, window enumerated z-major
-        return in[zo[n / 25] + yo[(n / 5) % 5] + xo[n % 5]];
-    };
-    float a[64];
+    float a[128];
 #pragma unroll
-    for (int q = 0; q < 64; q++) a[q] = sample(q);
-    Round<64>::run(a, sample);
-    // median of the last three
-    float lo = fminf(a[0], a[1]), hi = fmaxf(a[0], a[1]);
-    out[t] = fmaxf(lo, fminf(hi, a[2]));
+    for (int n = 0; n < 125; n++) a[n] = in[zo[n / 25] + yo[(n / 5) % 5] + xo[n % 5]];
+    a[125] = a[126] = a[127] = __builtin_inff();  // padding sorts to the top: rank 62 is unchanged
+    OESort<0, 128>::run(a);
+    out[t] = a[62];
 }
 
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out)

@@ -19,6 +19,9 @@
 // voxel's own old value"; the psi_data update (:356-377) is pointwise in the old increment, so it
 // is evaluated inside the sweep on iterations with t % update_lag == 0 and stored as w*psi;
 // the u,v,w part of the stencil is iteration-invariant and precomputed once (k_laplace).
+#include <algorithm>
+#include <cstdlib>
+
 #include "fr3d_internal.h"
 
 namespace fr3d {
@@ -33,52 +36,68 @@ template <> __device__ __forceinline__ double fma_<double>(double a, double b, d
 
 template <typename R, int C>
 __global__ void __launch_bounds__(SOR_BX * SOR_BY)
-k_sor_step(const SorArgs a, int tau, int t_lo)
+k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent)
 {
     const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X, Yp = a.sk.Yp;
     const long long plane = a.sk.plane;
-    const int t = t_lo + blockIdx.z;
+    // blockIdx.x enumerates the tiles of all in-flight iterations (schedule built on the host):
+    // find the iteration by bisection on the tile prefix, then the tile inside its bounding box
+    const int vol = blockIdx.y;
+    const int b = blockIdx.x;
+    int lo = 0, hi = nt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ent[mid].pre <= b) lo = mid;
+        else hi = mid - 1;
+    }
+    const SorEntry en = ent[lo];
+    const int local = b - en.pre;
+    const int t = t_lo + lo;
     const int s = tau - 2 * t;
-    const int k = blockIdx.y * SOR_BY + threadIdx.y;
-    const int j = blockIdx.x * SOR_BX + threadIdx.x;
+    const int k = (en.kb0 + local / en.njb) * SOR_BY + threadIdx.y;
+    const int j = (en.jb0 + local % en.njb) * SOR_BX + threadIdx.x;
     if (k >= Z || j >= Y) return;
     const int i = s - k - j;
     if (i < 0 || i >= X) return;
 
     const size_t c0 = (size_t)((long long)s * plane + (long long)k * Yp + j);
-    const R du0 = (R)a.d[0][c0], dv0 = (R)a.d[1][c0], dw0 = (R)a.d[2][c0];
+    const size_t oJ = c0 + (size_t)(vol * a.vsJ), oA = c0 + (size_t)(vol * a.vsA), oP = c0 + (size_t)(vol * a.vsP),
+                 oL = c0 + (size_t)(vol * a.vsL);
+    float *const dU = a.d[0] + vol * a.vsD, *const dV = a.d[1] + vol * a.vsD, *const dW = a.d[2] + vol * a.vsD;
+    const R du0 = (R)dU[c0], dv0 = (R)dV[c0], dw0 = (R)dW[c0];
 
     // neighbour sums; a ghost neighbour holds the voxel's own old value (set_boundary_3d)
     R su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z;
+    const bool nonb = a.dbg & 1;
     {
-        const bool hm = i > 0, hp = i < X - 1;
+        const bool hm = i > 0 && !nonb, hp = i < X - 1 && !nonb;
         const size_t m = c0 - (size_t)plane, p = c0 + (size_t)plane;
-        su_x = (hm ? (R)a.d[0][m] : du0) + (hp ? (R)a.d[0][p] : du0);
-        sv_x = (hm ? (R)a.d[1][m] : dv0) + (hp ? (R)a.d[1][p] : dv0);
-        sw_x = (hm ? (R)a.d[2][m] : dw0) + (hp ? (R)a.d[2][p] : dw0);
+        su_x = (hm ? (R)dU[m] : du0) + (hp ? (R)dU[p] : du0);
+        sv_x = (hm ? (R)dV[m] : dv0) + (hp ? (R)dV[p] : dv0);
+        sw_x = (hm ? (R)dW[m] : dw0) + (hp ? (R)dW[p] : dw0);
     }
     {
-        const bool hm = j > 0, hp = j < Y - 1;
+        const bool hm = j > 0 && !nonb, hp = j < Y - 1 && !nonb;
         const size_t m = c0 - (size_t)plane - 1, p = c0 + (size_t)plane + 1;
-        su_y = (hm ? (R)a.d[0][m] : du0) + (hp ? (R)a.d[0][p] : du0);
-        sv_y = (hm ? (R)a.d[1][m] : dv0) + (hp ? (R)a.d[1][p] : dv0);
-        sw_y = (hm ? (R)a.d[2][m] : dw0) + (hp ? (R)a.d[2][p] : dw0);
+        su_y = (hm ? (R)dU[m] : du0) + (hp ? (R)dU[p] : du0);
+        sv_y = (hm ? (R)dV[m] : dv0) + (hp ? (R)dV[p] : dv0);
+        sw_y = (hm ? (R)dW[m] : dw0) + (hp ? (R)dW[p] : dw0);
     }
     {
-        const bool hm = k > 0, hp = k < Z - 1;
+        const bool hm = k > 0 && !nonb, hp = k < Z - 1 && !nonb;
         const size_t m = c0 - (size_t)plane - Yp, p = c0 + (size_t)plane + Yp;
-        su_z = (hm ? (R)a.d[0][m] : du0) + (hp ? (R)a.d[0][p] : du0);
-        sv_z = (hm ? (R)a.d[1][m] : dv0) + (hp ? (R)a.d[1][p] : dv0);
-        sw_z = (hm ? (R)a.d[2][m] : dw0) + (hp ? (R)a.d[2][p] : dw0);
+        su_z = (hm ? (R)dU[m] : du0) + (hp ? (R)dU[p] : du0);
+        sv_z = (hm ? (R)dV[m] : dv0) + (hp ? (R)dV[p] : dv0);
+        sw_z = (hm ? (R)dW[m] : dw0) + (hp ? (R)dW[p] : dw0);
     }
     const R ax = (R)a.ax, ay = (R)a.ay, az = (R)a.az;
-    R num_u = fma_<R>(az, su_z, fma_<R>(ay, su_y, fma_<R>(ax, su_x, (R)a.L[0][c0])));
-    R num_v = fma_<R>(az, sv_z, fma_<R>(ay, sv_y, fma_<R>(ax, sv_x, (R)a.L[1][c0])));
-    R num_w = fma_<R>(az, sw_z, fma_<R>(ay, sw_y, fma_<R>(ax, sw_x, (R)a.L[2][c0])));
+    R num_u = fma_<R>(az, su_z, fma_<R>(ay, su_y, fma_<R>(ax, su_x, (R)a.L[0][oL])));
+    R num_v = fma_<R>(az, sv_z, fma_<R>(ay, sv_y, fma_<R>(ax, sv_x, (R)a.L[1][oL])));
+    R num_w = fma_<R>(az, sw_z, fma_<R>(ay, sw_y, fma_<R>(ax, sw_x, (R)a.L[2][oL])));
     const R diag = (R)(2.0 * a.ax + 2.0 * a.ay + 2.0 * a.az);
     R den_u = diag, den_v = diag, den_w = diag;
 
-    const bool upd = (t % a.update_lag) == 0;
+    const bool upd = (t % a.update_lag) == 0 && !(a.dbg & 4);
     R j12[C], j13[C], j23[C], ww[C];
     R bu = 0, bv = 0, bw = 0;  // sum_c ww*J14, ww*J24, ww*J34
 #pragma unroll
@@ -92,7 +111,7 @@ k_sor_step(const SorArgs a, int tau, int t_lo)
             // rebuilt from the same factors instead of being read.
             float f[12];
 #pragma unroll
-            for (int q = 0; q < 12; q++) f[q] = a.A[q * FR3D_MAX_CHANNELS + c][c0];
+            for (int q = 0; q < 12; q++) f[q] = a.A[q * FR3D_MAX_CHANNELS + c][oA];
             double wt = (double)a.weight[c][c0];
             const double adc = a.a_data[c];
             if (adc != 1.0) {
@@ -104,10 +123,12 @@ k_sor_step(const SorArgs a, int tau, int t_lo)
                                    fma((double)f[4 * k + 2], w_, (double)f[4 * k + 3])));
                     val = fma(r, r, val);
                 }
-                wt *= adc * pow(val + 1e-6, adc - 1.0);
+                // fp32 powf (~1 ulp): w*psi is stored in fp32 anyway, and the fp64 pow's ~600-instruction
+                // dependent chain set a ~6 us latency floor on every launch
+                wt *= adc * (double)powf((float)(val + 1e-6), (float)(adc - 1.0));
             }
             const float wf = (float)wt;
-            a.wpsi[c][c0] = wf;
+            a.wpsi[c][oP] = wf;
             w = (R)wf;
             const R x0 = (R)f[0], x1 = (R)f[1], x2 = (R)f[2], x3 = (R)f[3];
             const R y0 = (R)f[4], y1 = (R)f[5], y2 = (R)f[6], y3 = (R)f[7];
@@ -122,16 +143,16 @@ k_sor_step(const SorArgs a, int tau, int t_lo)
             J24 = fma_<R>(z1, z3, fma_<R>(y1, y3, x1 * x3));
             J34 = fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3));
         } else {
-            J11 = (R)a.J[0 * FR3D_MAX_CHANNELS + c][c0];
-            J22 = (R)a.J[1 * FR3D_MAX_CHANNELS + c][c0];
-            J33 = (R)a.J[2 * FR3D_MAX_CHANNELS + c][c0];
-            J12 = (R)a.J[3 * FR3D_MAX_CHANNELS + c][c0];
-            J13 = (R)a.J[4 * FR3D_MAX_CHANNELS + c][c0];
-            J23 = (R)a.J[5 * FR3D_MAX_CHANNELS + c][c0];
-            J14 = (R)a.J[6 * FR3D_MAX_CHANNELS + c][c0];
-            J24 = (R)a.J[7 * FR3D_MAX_CHANNELS + c][c0];
-            J34 = (R)a.J[8 * FR3D_MAX_CHANNELS + c][c0];
-            w = (R)a.wpsi[c][c0];
+            J11 = (R)a.J[0 * FR3D_MAX_CHANNELS + c][oJ];
+            J22 = (R)a.J[1 * FR3D_MAX_CHANNELS + c][oJ];
+            J33 = (R)a.J[2 * FR3D_MAX_CHANNELS + c][oJ];
+            J12 = (R)a.J[3 * FR3D_MAX_CHANNELS + c][oJ];
+            J13 = (R)a.J[4 * FR3D_MAX_CHANNELS + c][oJ];
+            J23 = (R)a.J[5 * FR3D_MAX_CHANNELS + c][oJ];
+            J14 = (R)a.J[6 * FR3D_MAX_CHANNELS + c][oJ];
+            J24 = (R)a.J[7 * FR3D_MAX_CHANNELS + c][oJ];
+            J34 = (R)a.J[8 * FR3D_MAX_CHANNELS + c][oJ];
+            w = (R)a.wpsi[c][oP];
         }
         ww[c] = w;
         j12[c] = J12; j13[c] = J13; j23[c] = J23;
@@ -160,29 +181,31 @@ k_sor_step(const SorArgs a, int tau, int t_lo)
     for (int c = 0; c < C; c++) n2 -= ww[c] * fma_<R>(j23[c], dv1, j13[c] * du1);
     const R dw1 = fma_<R>(om, (den_w != (R)0 ? n2 / den_w : (R)0), om1 * dw0);
 
-    a.d[0][c0] = (float)du1;
-    a.d[1][c0] = (float)dv1;
-    a.d[2][c0] = (float)dw1;
+    dU[c0] = (float)du1;
+    dV[c0] = (float)dv1;
+    dW[c0] = (float)dw1;
 }
 
 template <typename R>
-static void launch_step(hipStream_t st, const SorArgs &a, int tau, int t_lo, int nt)
+static void launch_step(hipStream_t st, const SorArgs &a, int tau, int t_lo, int nt, int ntiles,
+                        const SorEntry *ent)
 {
-    dim3 grid(cdiv(a.sk.Y, SOR_BX), cdiv(a.sk.Z, SOR_BY), nt), block(SOR_BX, SOR_BY);
+    dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, SOR_BY);
     switch (a.C) {
-        case 1: hipLaunchKernelGGL((k_sor_step<R, 1>), grid, block, 0, st, a, tau, t_lo); break;
-        case 2: hipLaunchKernelGGL((k_sor_step<R, 2>), grid, block, 0, st, a, tau, t_lo); break;
-        case 3: hipLaunchKernelGGL((k_sor_step<R, 3>), grid, block, 0, st, a, tau, t_lo); break;
-        case 4: hipLaunchKernelGGL((k_sor_step<R, 4>), grid, block, 0, st, a, tau, t_lo); break;
+        case 1: hipLaunchKernelGGL((k_sor_step<R, 1>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
+        case 2: hipLaunchKernelGGL((k_sor_step<R, 2>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
+        case 3: hipLaunchKernelGGL((k_sor_step<R, 3>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
+        case 4: hipLaunchKernelGGL((k_sor_step<R, 4>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
         default: throw Error("SOR kernel is instantiated for 1..4 channels");
     }
 }
 
-long long launch_sor(hipStream_t st, const SorArgs &a, bool fp64)
+SorSched build_sor_schedule(const Skew &sk, int T)
 {
-    const int S = a.sk.S, T = a.iterations;
-    if (T <= 0) return 0;
-    long long launches = 0;
+    SorSched sc;
+    const int S = sk.S, Z = sk.Z, Y = sk.Y, X = sk.X;
+    std::vector<SorEntry> ent;
+    if (T <= 0) return sc;
     const int last = (S - 1) + 2 * (T - 1);
     for (int tau = 0; tau <= last; tau++) {
         int t_lo = tau - (S - 1);
@@ -190,8 +213,55 @@ long long launch_sor(hipStream_t st, const SorArgs &a, bool fp64)
         int t_hi = tau / 2;
         if (t_hi > T - 1) t_hi = T - 1;
         if (t_lo > t_hi) continue;
-        if (fp64) launch_step<double>(st, a, tau, t_lo, t_hi - t_lo + 1);
-        else launch_step<float>(st, a, tau, t_lo, t_hi - t_lo + 1);
+        sc.tau.push_back(tau);
+        sc.t_lo.push_back(t_lo);
+        sc.nt.push_back(t_hi - t_lo + 1);
+        sc.first.push_back((int)ent.size());
+        int pre = 0;
+        for (int t = t_lo; t <= t_hi; t++) {
+            const int s = tau - 2 * t;
+            // valid voxels of hyperplane s: k in [klo,khi], j in [s-k-(X-1), s-k] clipped to [0,Y-1]
+            const int klo = std::max(0, s - (X - 1) - (Y - 1)), khi = std::min(Z - 1, s);
+            const int jlo = std::max(0, s - khi - (X - 1)), jhi = std::min(Y - 1, s - klo);
+            SorEntry e;
+            e.pre = pre;
+            e.pad = 0;
+            if (klo > khi || jlo > jhi) {
+                e.kb0 = e.jb0 = 0;
+                e.njb = 1;
+            } else {
+                const int kb0 = klo / SOR_BY, kb1 = khi / SOR_BY, jb0 = jlo / SOR_BX, jb1 = jhi / SOR_BX;
+                e.kb0 = (short)kb0;
+                e.jb0 = (short)jb0;
+                e.njb = (short)(jb1 - jb0 + 1);
+                pre += (kb1 - kb0 + 1) * (jb1 - jb0 + 1);
+            }
+            ent.push_back(e);
+        }
+        sc.ntiles.push_back(pre);
+    }
+    FR3D_HIP(hipMalloc((void **)&sc.entries, ent.size() * sizeof(SorEntry)));
+    FR3D_HIP(hipMemcpy(sc.entries, ent.data(), ent.size() * sizeof(SorEntry), hipMemcpyHostToDevice));
+    return sc;
+}
+
+void free_sor_schedule(SorSched &s)
+{
+    if (s.entries) (void)hipFree(s.entries);
+    s.entries = nullptr;
+}
+
+long long launch_sor(hipStream_t st, const SorArgs &a_in, bool fp64, const SorSched &sc)
+{
+    SorArgs a = a_in;
+    static const char *dbg_env = getenv("FR3D_SOR_DBG");
+    a.dbg = dbg_env ? atoi(dbg_env) : 0;
+    long long launches = 0;
+    for (size_t l = 0; l < sc.tau.size(); l++) {
+        if (sc.ntiles[l] <= 0) continue;
+        const SorEntry *ent = sc.entries + sc.first[l];
+        if (fp64) launch_step<double>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent);
+        else launch_step<float>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent);
         launches++;
     }
     return launches;
