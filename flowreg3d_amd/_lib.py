@@ -18,7 +18,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflowreg3d_hip.so")
+LIB_PATH = os.environ.get("FR3D_LIB") or os.path.join(_HERE, "lib", "libflowreg3d_hip.so")  # FR3D_LIB: A/B builds
 MAX_CHANNELS = 8
 F32, F64 = 0, 1
 

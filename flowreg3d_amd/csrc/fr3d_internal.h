@@ -35,11 +35,15 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // ---------------------------------------------------------------------------------------------
 // Skewed ("hyperplane-major") layout used by the SOR sweep.
 //
-// Interior voxel (k,j,i) = (z,y,x) of a level lives at  s*plane + k*Yp + j  with s = i+j+k.
-// All voxels of one lexicographic-Gauss-Seidel wavefront (constant s) are then contiguous in j
-// for fixed k, and the six stencil neighbours are at constant offsets:
-//   (k,j,i-1) -> -plane      (k,j-1,i) -> -plane-1     (k-1,j,i) -> -plane-Yp
-//   (k,j,i+1) -> +plane      (k,j+1,i) -> +plane+1     (k+1,j,i) -> +plane+Yp
+// Interior voxel (k,j,i) = (z,y,x) of a level lives at  s*plane + k*Yp + (j - jm(s-k))  with
+// s = i+j+k and jm(r) = max(0, r-(X-1)) the first valid j of row (s,k): rows are LEFT-ALIGNED, so
+// the valid voxels of a row start at a 256-B boundary (one partly used cache line per row instead
+// of two, and only the last 64-lane tile of a row is partly filled).  All voxels of one
+// lexicographic-Gauss-Seidel wavefront (constant s) are contiguous in j for fixed k, and the six
+// stencil neighbours are at row-uniform offsets (d1 = jm(r)-jm(r-1) in {0,1}, d2 = jm(r)-jm(r+1)
+// in {0,-1}, r = s-k):
+//   (k,j,i-1) -> -plane+d1   (k,j-1,i) -> -plane+d1-1  (k-1,j,i) -> -plane-Yp
+//   (k,j,i+1) -> +plane+d2   (k,j+1,i) -> +plane+d2+1  (k+1,j,i) -> +plane+Yp
 // Storage is S*Z*Yp elements (S = X+Y+Z-2 hyperplanes): ~3x the voxel count for a cube; only the
 // valid third is ever touched, so it costs HBM capacity (288 GB), not bandwidth.
 // ---------------------------------------------------------------------------------------------
@@ -50,6 +54,13 @@ struct Skew {
     long long plane;  // Z*Yp
     long long total;  // S*plane
 };
+
+__host__ __device__ static inline int sk_jm(int X, int r) { return r > X - 1 ? r - (X - 1) : 0; }
+// storage index of interior voxel (z,y,x)
+__host__ __device__ static inline long long sk_index(int X, int Yp, long long plane, int z, int y, int x)
+{
+    return (long long)(x + y + z) * plane + (long long)z * Yp + (y - sk_jm(X, x + y));
+}
 
 static inline Skew make_skew(int Z, int Y, int X)
 {
@@ -123,8 +134,8 @@ void launch_laplace(hipStream_t st, const float *u, const float *v, const float 
 // can hold voxels are dispatched (an all-covering grid spends ~8 us per launch on empty workgroups).
 struct SorEntry {
     int pre;               // tiles of this launch before this iteration
-    short kb0, jb0, njb;   // first k-tile, first j-tile, j-tiles per k-tile row
-    short pad;
+    short kb0, njb;        // first k-tile, j-tiles per k-tile row (rows are left-aligned)
+    short pad0, pad1;
 };
 struct SorSched {
     std::vector<int> tau, t_lo, nt, first, ntiles;  // per launch

@@ -28,7 +28,9 @@ namespace fr3d {
 
 #define SOR_OMEGA 1.95
 #define SOR_BX 64
+#ifndef SOR_BY
 #define SOR_BY 4
+#endif
 
 template <typename R> __device__ __forceinline__ R fma_(R a, R b, R c);
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
@@ -55,12 +57,16 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
     const int t = t_lo + lo;
     const int s = tau - 2 * t;
     const int k = (en.kb0 + local / en.njb) * SOR_BY + threadIdx.y;
-    const int j = (en.jb0 + local % en.njb) * SOR_BX + threadIdx.x;
-    if (k >= Z || j >= Y) return;
-    const int i = s - k - j;
-    if (i < 0 || i >= X) return;
+    if (k >= Z) return;
+    const int r = s - k;                       // i + j of this row
+    const int jm0 = sk_jm(X, r);               // first valid j of the row (left-aligned storage)
+    const int jj = (local % en.njb) * SOR_BX + threadIdx.x;
+    const int j = jj + jm0;
+    const int i = r - j;
+    if (r < 0 || j >= Y || i < 0) return;      // i < X holds by construction of jm0
 
-    const size_t c0 = (size_t)((long long)s * plane + (long long)k * Yp + j);
+    const size_t c0 = (size_t)((long long)s * plane + (long long)k * Yp + jj);
+    const long long d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
     const size_t oJ = c0 + (size_t)(vol * a.vsJ), oA = c0 + (size_t)(vol * a.vsA), oP = c0 + (size_t)(vol * a.vsP),
                  oL = c0 + (size_t)(vol * a.vsL);
     float *const dU = a.d[0] + vol * a.vsD, *const dV = a.d[1] + vol * a.vsD, *const dW = a.d[2] + vol * a.vsD;
@@ -71,14 +77,14 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
     const bool nonb = a.dbg & 1;
     {
         const bool hm = i > 0 && !nonb, hp = i < X - 1 && !nonb;
-        const size_t m = c0 - (size_t)plane, p = c0 + (size_t)plane;
+        const size_t m = (size_t)((long long)c0 - plane + d1), p = (size_t)((long long)c0 + plane + d2);
         su_x = (hm ? (R)dU[m] : du0) + (hp ? (R)dU[p] : du0);
         sv_x = (hm ? (R)dV[m] : dv0) + (hp ? (R)dV[p] : dv0);
         sw_x = (hm ? (R)dW[m] : dw0) + (hp ? (R)dW[p] : dw0);
     }
     {
         const bool hm = j > 0 && !nonb, hp = j < Y - 1 && !nonb;
-        const size_t m = c0 - (size_t)plane - 1, p = c0 + (size_t)plane + 1;
+        const size_t m = (size_t)((long long)c0 - plane + d1 - 1), p = (size_t)((long long)c0 + plane + d2 + 1);
         su_y = (hm ? (R)dU[m] : du0) + (hp ? (R)dU[p] : du0);
         sv_y = (hm ? (R)dV[m] : dv0) + (hp ? (R)dV[p] : dv0);
         sw_y = (hm ? (R)dW[m] : dw0) + (hp ? (R)dW[p] : dw0);
@@ -220,21 +226,28 @@ SorSched build_sor_schedule(const Skew &sk, int T)
         int pre = 0;
         for (int t = t_lo; t <= t_hi; t++) {
             const int s = tau - 2 * t;
-            // valid voxels of hyperplane s: k in [klo,khi], j in [s-k-(X-1), s-k] clipped to [0,Y-1]
+            // valid rows of hyperplane s: k in [klo,khi]; row (s,k) holds r = s-k, j in
+            // [jm(r), min(Y-1,r)], stored left-aligned, so tiles start at 0 and the row count of
+            // j-tiles is set by the longest row
             const int klo = std::max(0, s - (X - 1) - (Y - 1)), khi = std::min(Z - 1, s);
-            const int jlo = std::max(0, s - khi - (X - 1)), jhi = std::min(Y - 1, s - klo);
             SorEntry e;
             e.pre = pre;
-            e.pad = 0;
-            if (klo > khi || jlo > jhi) {
-                e.kb0 = e.jb0 = 0;
-                e.njb = 1;
-            } else {
-                const int kb0 = klo / SOR_BY, kb1 = khi / SOR_BY, jb0 = jlo / SOR_BX, jb1 = jhi / SOR_BX;
-                e.kb0 = (short)kb0;
-                e.jb0 = (short)jb0;
-                e.njb = (short)(jb1 - jb0 + 1);
-                pre += (kb1 - kb0 + 1) * (jb1 - jb0 + 1);
+            e.pad0 = e.pad1 = 0;
+            e.kb0 = 0;
+            e.njb = 1;
+            if (klo <= khi) {
+                int maxlen = 0;
+                for (int k = klo; k <= khi; k++) {
+                    const int r = s - k;
+                    const int len = std::min(Y - 1, r) - sk_jm(X, r) + 1;
+                    if (len > maxlen) maxlen = len;
+                }
+                if (maxlen > 0) {
+                    const int kb0 = klo / SOR_BY, kb1 = khi / SOR_BY;
+                    e.kb0 = (short)kb0;
+                    e.njb = (short)cdiv(maxlen, SOR_BX);
+                    pre += (kb1 - kb0 + 1) * e.njb;
+                }
             }
             ent.push_back(e);
         }
@@ -280,7 +293,7 @@ k_skew_copy(const float *__restrict__ src, int Z, int Y, int X, int Yp, long lon
     long long r = t / X;
     int y = (int)(r % Y);
     int z = (int)(r / Y);
-    size_t o = (size_t)((long long)(x + y + z) * plane + (long long)z * Yp + y);
+    size_t o = (size_t)sk_index(X, Yp, plane, z, y, x);
     if (to_skew) dst[o] = src[t];
     else dst[t] = src[o];
 }
@@ -317,7 +330,7 @@ k_laplace(const float *__restrict__ u, const float *__restrict__ v, const float 
     const long long xm = x > 0 ? -sx : 0, xp = x < X - 1 ? sx : 0;
     const long long ym = y > 0 ? -sy : 0, yp = y < Y - 1 ? sy : 0;
     const long long zm = z > 0 ? -sz : 0, zp = z < Z - 1 ? sz : 0;
-    size_t o = (size_t)((long long)(x + y + z) * plane + (long long)z * Yp + y);
+    size_t o = (size_t)sk_index(X, Yp, plane, z, y, x);
     const float *f[3] = {u, v, w};
     float *L[3] = {Lu, Lv, Lw};
 #pragma unroll

@@ -79,7 +79,7 @@ k_motion_tensor(Img f1, Img f2, double hz, double hy, double hx, float *J11, flo
     double ry = 1.0 / (syn * syn + 1e-6);
     double rz = 1.0 / (szn * szn + 1e-6);
 
-    size_t o = skewed ? (size_t)((long long)(x + y + z) * plane + (long long)z * Yp + y) : (size_t)t;
+    size_t o = skewed ? (size_t)sk_index(X, Yp, plane, z, y, x) : (size_t)t;
     J11[o] = (float)(rx * (fxx * fxx) + ry * (fxy * fxy) + rz * (fxz * fxz));
     J22[o] = (float)(rx * (fxy * fxy) + ry * (fyy * fyy) + rz * (fyz * fyz));
     J33[o] = (float)(rx * (fxz * fxz) + ry * (fyz * fyz) + rz * (fzz * fzz));
