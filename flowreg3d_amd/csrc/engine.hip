@@ -474,22 +474,25 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
                 warped = wbuf;
             }
             {
+                // tensor + factors + Laplacian terms are produced in the natural layout (coalesced
+                // stores) and moved to the skewed layout by the LDS-tiled transpose, 24 arrays a launch
                 Span sp(e, FR3D_K_TENSOR, 4.0 * (2 + 21) * nl * C, C, (long long)nl * C);
+                float *nat = e.f32("JAL_nat", nl * 24);
                 for (int c = 0; c < C; c++) {
                     // reference order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 -> solver slots (J44 is
                     // not stored: psi comes from the factors)
-                    float *base = Jbuf + (size_t)b * a.vsJ + (size_t)c * 9 * ns;
-                    float *abase = Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns;
-                    float *Jo[10] = {base + 0 * ns, base + 1 * ns, base + 2 * ns, nullptr, base + 3 * ns,
-                                     base + 4 * ns, base + 5 * ns, base + 6 * ns, base + 7 * ns, base + 8 * ns};
+                    float *Jo[10] = {nat + 0 * nl, nat + 1 * nl, nat + 2 * nl, nullptr, nat + 3 * nl,
+                                     nat + 4 * nl, nat + 5 * nl, nat + 6 * nl, nat + 7 * nl, nat + 8 * nl};
                     launch_motion_tensor(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
-                                         hx, Jo, abase, (long long)ns, &sk);
+                                         hx, Jo, nat + 9 * nl, (long long)nl, nullptr);
+                    launch_skew_copy_n(e.st, nat, (long long)nl, Jbuf + (size_t)b * a.vsJ + (size_t)c * 9 * ns,
+                                       (long long)ns, 9, sk);
+                    launch_skew_copy_n(e.st, nat + 9 * nl, (long long)nl,
+                                       Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns, (long long)ns, 12, sk);
                 }
-            }
-            {
-                Span sp(e, FR3D_K_OTHER, 0, 0, 0);
-                float *Lb = Lbuf + (size_t)b * a.vsL;
-                launch_laplace(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Lb, Lb + ns, Lb + 2 * ns);
+                float *Ln = nat + 21 * nl;
+                launch_laplace(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Ln, Ln + nl, Ln + 2 * nl, true);
+                launch_skew_copy_n(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, (long long)ns, 3, sk);
             }
         }
         a.iterations = p.iterations;
@@ -507,8 +510,7 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
             float **u = &uvw[3 * b];
             {
                 Span sp(e, FR3D_K_OTHER, 0, 0, 0);
-                for (int d = 0; d < 3; d++)
-                    launch_unskew_copy(e.st, dbuf + (size_t)b * a.vsD + (size_t)d * ns, sk, dn + (size_t)d * nl);
+                launch_unskew_copy_n(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
             }
             if (med) {
                 Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);

@@ -127,8 +127,14 @@ void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int 
 // K4-K7 SOR
 void launch_skew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst);
 void launch_unskew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst);
+// narr arrays, src_stride / dst_stride elements apart
+void launch_skew_copy_n(hipStream_t st, const float *src, long long src_stride, float *dst,
+                        long long dst_stride, int narr, const Skew &sk);
+void launch_unskew_copy_n(hipStream_t st, const float *src, long long src_stride, float *dst,
+                          long long dst_stride, int narr, const Skew &sk);
+// natural = true writes L in the natural (Z,Y,X) layout instead of the skewed one
 void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
-                    double ax, double ay, double az, float *Lu, float *Lv, float *Lw);
+                    double ax, double ay, double az, float *Lu, float *Lv, float *Lw, bool natural = false);
 // Launch schedule of one level geometry: for every launch tau and every in-flight iteration t the
 // bounding box (in tile units) of the valid part of hyperplane s = tau - 2t, so that only tiles that
 // can hold voxels are dispatched (an all-covering grid spends ~8 us per launch on empty workgroups).

@@ -282,34 +282,76 @@ long long launch_sor(hipStream_t st, const SorArgs &a_in, bool fp64, const SorSc
 
 // ---- layout conversion and the iteration-invariant stencil part -------------------------------
 
+// Natural (Z,Y,X) <-> skewed layout for `narr` arrays at once, through a 64x64 LDS tile of one
+// z-slice: the natural side moves as 256-B row segments (x contiguous), the skewed side as runs
+// along the tile's anti-diagonals (x+y constant => same hyperplane and row, j contiguous), so both
+// sides are coalesced.  A direct scatter costs ~8x write amplification (4-B writes, 128-B lines).
+#define SKT 64
 __global__ void __launch_bounds__(256)
-k_skew_copy(const float *__restrict__ src, int Z, int Y, int X, int Yp, long long plane,
-            float *__restrict__ dst, int to_skew)
+k_skew_tiled(const float *__restrict__ src, long long src_stride, float *__restrict__ dst,
+             long long dst_stride, int Z, int Y, int X, int Yp, long long plane, int to_skew)
 {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long total = (long long)Z * Y * X;
-    if (t >= total) return;
-    int x = (int)(t % X);
-    long long r = t / X;
-    int y = (int)(r % Y);
-    int z = (int)(r / Y);
-    size_t o = (size_t)sk_index(X, Yp, plane, z, y, x);
-    if (to_skew) dst[o] = src[t];
-    else dst[t] = src[o];
+    __shared__ float tile[SKT][SKT + 2];
+    const int txn = (X + SKT - 1) / SKT;
+    const int x0 = (blockIdx.x % txn) * SKT, y0 = (blockIdx.x / txn) * SKT;
+    const int z = blockIdx.y;
+    src += (size_t)blockIdx.z * src_stride;
+    dst += (size_t)blockIdx.z * dst_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (to_skew) {
+        for (int row = wave; row < SKT; row += 4) {
+            const int y = y0 + row, x = x0 + lane;
+            if (y < Y && x < X) tile[row][lane] = src[((size_t)z * Y + y) * X + x];
+        }
+        __syncthreads();
+        for (int d = wave; d < 2 * SKT - 1; d += 4) {
+            const int ly = lane, lx = d - lane;
+            const int y = y0 + ly, x = x0 + lx;
+            if (lx >= 0 && lx < SKT && y < Y && x < X) dst[(size_t)sk_index(X, Yp, plane, z, y, x)] = tile[ly][lx];
+        }
+    } else {
+        for (int d = wave; d < 2 * SKT - 1; d += 4) {
+            const int ly = lane, lx = d - lane;
+            const int y = y0 + ly, x = x0 + lx;
+            if (lx >= 0 && lx < SKT && y < Y && x < X) tile[ly][lx] = src[(size_t)sk_index(X, Yp, plane, z, y, x)];
+        }
+        __syncthreads();
+        for (int row = wave; row < SKT; row += 4) {
+            const int y = y0 + row, x = x0 + lane;
+            if (y < Y && x < X) dst[((size_t)z * Y + y) * X + x] = tile[row][lane];
+        }
+    }
+}
+
+static void launch_skew_tiled(hipStream_t st, const float *src, long long src_stride, float *dst,
+                              long long dst_stride, int narr, const Skew &sk, int to_skew)
+{
+    if (narr <= 0) return;
+    dim3 grid(cdiv(sk.X, SKT) * cdiv(sk.Y, SKT), sk.Z, narr);
+    hipLaunchKernelGGL(k_skew_tiled, grid, dim3(256), 0, st, src, src_stride, dst, dst_stride, sk.Z, sk.Y,
+                       sk.X, sk.Yp, sk.plane, to_skew);
 }
 
 void launch_skew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst)
 {
-    long long total = (long long)sk.Z * sk.Y * sk.X;
-    hipLaunchKernelGGL(k_skew_copy, dim3(cdiv(total, 256)), dim3(256), 0, st, src, sk.Z, sk.Y, sk.X,
-                       sk.Yp, sk.plane, dst, 1);
+    launch_skew_tiled(st, src, 0, dst, 0, 1, sk, 1);
 }
 
 void launch_unskew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst)
 {
-    long long total = (long long)sk.Z * sk.Y * sk.X;
-    hipLaunchKernelGGL(k_skew_copy, dim3(cdiv(total, 256)), dim3(256), 0, st, src, sk.Z, sk.Y, sk.X,
-                       sk.Yp, sk.plane, dst, 0);
+    launch_skew_tiled(st, src, 0, dst, 0, 1, sk, 0);
+}
+
+void launch_skew_copy_n(hipStream_t st, const float *src, long long src_stride, float *dst,
+                        long long dst_stride, int narr, const Skew &sk)
+{
+    launch_skew_tiled(st, src, src_stride, dst, dst_stride, narr, sk, 1);
+}
+
+void launch_unskew_copy_n(hipStream_t st, const float *src, long long src_stride, float *dst,
+                          long long dst_stride, int narr, const Skew &sk)
+{
+    launch_skew_tiled(st, src, src_stride, dst, dst_stride, narr, sk, 0);
 }
 
 // L = ax*(u_ip + u_im - 2u) + ay*(...) + az*(...) with edge-padded u (add_boundary,
@@ -330,7 +372,7 @@ k_laplace(const float *__restrict__ u, const float *__restrict__ v, const float 
     const long long xm = x > 0 ? -sx : 0, xp = x < X - 1 ? sx : 0;
     const long long ym = y > 0 ? -sy : 0, yp = y < Y - 1 ? sy : 0;
     const long long zm = z > 0 ? -sz : 0, zp = z < Z - 1 ? sz : 0;
-    size_t o = (size_t)sk_index(X, Yp, plane, z, y, x);
+    size_t o = plane ? (size_t)sk_index(X, Yp, plane, z, y, x) : (size_t)t;
     const float *f[3] = {u, v, w};
     float *L[3] = {Lu, Lv, Lw};
 #pragma unroll
@@ -345,11 +387,11 @@ k_laplace(const float *__restrict__ u, const float *__restrict__ v, const float 
 }
 
 void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
-                    double ax, double ay, double az, float *Lu, float *Lv, float *Lw)
+                    double ax, double ay, double az, float *Lu, float *Lv, float *Lw, bool natural)
 {
     long long total = (long long)sk.Z * sk.Y * sk.X;
     hipLaunchKernelGGL(k_laplace, dim3(cdiv(total, 256)), dim3(256), 0, st, u, v, w, sk.Z, sk.Y,
-                       sk.X, sk.Yp, sk.plane, ax, ay, az, Lu, Lv, Lw);
+                       sk.X, sk.Yp, natural ? 0LL : sk.plane, ax, ay, az, Lu, Lv, Lw);
 }
 
 }  // namespace fr3d
