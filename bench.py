@@ -104,17 +104,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    dev_index = local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # "nccl" is RCCL on ROCm.  FR3D_DIST_BACKEND=gloo lets the N>1 path be rehearsed on a
+        # one-GPU box (ranks then share device 0); it is never used for reported numbers.
+        backend = os.environ.get("FR3D_DIST_BACKEND", "nccl")
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from flowreg3d_amd import _lib
     from flowreg3d_amd.synthetic import flow_gt, texture
-    lib = _lib.init(local_rank)
+    lib = _lib.init(dev_index)
 
     Z, Y, X, levels, desc = WORKLOADS[args.workload]
     nv = Z * Y * X
@@ -127,7 +135,7 @@ def main():
     ref_dev = DevArray(lib, (Z, Y, X, 1))
     if world > 1:
         import torch
-        ref_t = torch.empty((Z, Y, X), dtype=torch.float32, device=f"cuda:{local_rank}")
+        ref_t = torch.empty((Z, Y, X), dtype=torch.float32, device=f"cuda:{dev_index}")
         if rank == 0:
             ref_t.copy_(torch.from_numpy(texture((Z, Y, X), seed=1234)))
         dist.broadcast(ref_t, src=0)  # the path's only collective
@@ -180,12 +188,22 @@ def main():
     lib.fr3d_prof_enable(0)
     if world > 1:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     if rank == 0:
         sor = stats["sor"]
+        # HBM traffic of the SOR kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 per
+        # the gfx950 correction, + WRITE_SIZE; tools/gpu_measure.sh), stored per voxel update
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                pmc = json.load(fh).get(args.workload)
+            if pmc:
+                traffic = pmc["bytes_per_update"] * sor["units"] / max(sor["launches"], 1)
+        except (OSError, ValueError, KeyError):
+            traffic = None
         achieved = sor["algo_bytes"] / (sor["ms"] * 1e-3) / 1e9 if sor["ms"] > 0 else 0.0
         out = {
             "metric": "volumes/sec (3D flow solve + warp)",
@@ -206,7 +224,7 @@ def main():
                        "sharding": f"volume-per-GPU x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_sor_step (SOR hyperplane sweep)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algo_bytes_per_launch": sor["algo_bytes"] / max(sor["launches"], 1),
                          "avg_launch_us": 1e3 * sor["ms"] / max(sor["launches"], 1),
                          "launches": sor["launches"]},
