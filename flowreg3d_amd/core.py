@@ -250,9 +250,6 @@ def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v,
         if not np.array_equal(a, np.pad(a[inner], 1, mode="edge")):
             raise NotImplementedError("u, v, w must be edge-padded (add_boundary) as in get_displacement")
     Ji = [np.moveaxis(j[inner], -1, 0) for j in Js]  # each (C,Z,Y,X)
-    Jd = np.empty((9, nc, P - 2, M - 2, N - 2), np.float32)
-    for slot, k in enumerate((0, 1, 2, 4, 5, 6, 7, 8, 9)):
-        Jd[slot] = Ji[k]
     Ad = _f32c(tensor_factors(*Ji))  # (12,C,Z,Y,X)
     wd = _f32c(np.moveaxis(wt[inner], -1, 0))
     uvw = np.stack([np.asarray(a)[inner] for a in (u, v, w)], 0).astype(np.float32)
@@ -261,7 +258,7 @@ def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v,
     ad_np = np.broadcast_to(np.asarray(a_data, dtype=np.float64).reshape(-1), (nc,))
     ad = (C.c_double * nc)(*[float(x) for x in ad_np])
     lib = _lib.init()
-    _lib.check(lib.fr3d_level_solve(_lib.ptr(Jd), _lib.ptr(Ad), _lib.ptr(wd), _lib.ptr(uvw), P - 2, M - 2, N - 2,
+    _lib.check(lib.fr3d_level_solve(_lib.ptr(Ad), _lib.ptr(wd), _lib.ptr(uvw), P - 2, M - 2, N - 2,
                                     nc, al, int(iterations), int(update_lag), ad, float(hx), float(hy),
                                     float(hz), 1 if solver_fp64 else 0, _lib.ptr(out)))
     return tuple(np.pad(out[d].astype(np.float64), 1, mode="edge") for d in range(3))

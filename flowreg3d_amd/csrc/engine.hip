@@ -408,10 +408,9 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
         const Skew sk = make_skew(lz, ly, lx);
         const size_t ns = (size_t)sk.total;
         const size_t nres = (size_t)std::max(nb, reserve_nb);  // slabs reserved (>= nb)
-        float *Jbuf = e.f32("J_sk", ns * 9 * C * nres);
+        float *Mbuf = e.f32("M_sk", ns * 9 * nres);
         float *Abuf = e.f32("A_sk", ns * 12 * C * nres);
         float *wsk = e.f32("w_sk", ns * C);
-        float *wpsi = e.f32("wpsi_sk", ns * C * nres);
         float *Lbuf = e.f32("L_sk", ns * 3 * nres);
         float *dbuf = e.f32("d_sk", ns * 3 * nres);
         SorArgs a;
@@ -419,9 +418,8 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
         a.sk = sk;
         a.C = C;
         a.nvol = nb;
-        a.vsJ = (long long)ns * 9 * C;
+        a.vsM = (long long)ns * 9;
         a.vsA = (long long)ns * 12 * C;
-        a.vsP = (long long)ns * C;
         a.vsL = (long long)ns * 3;
         a.vsD = (long long)ns * 3;
         // alpha schedule (:485-490) and alpha/h^2 (level_solver_3d.py:473-475)
@@ -430,12 +428,11 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
         a.ay = (sc * p.alpha[1]) / (hy * hy);
         a.az = (sc * p.alpha[2]) / (hz * hz);
         for (int c = 0; c < C; c++) {
-            for (int q = 0; q < 9; q++) a.J[q * FR3D_MAX_CHANNELS + c] = Jbuf + ((size_t)c * 9 + q) * ns;
             for (int q = 0; q < 12; q++) a.A[q * FR3D_MAX_CHANNELS + c] = Abuf + ((size_t)c * 12 + q) * ns;
             a.weight[c] = wsk + (size_t)c * ns;
-            a.wpsi[c] = wpsi + (size_t)c * ns;
             a.a_data[c] = p.a_data[c];
         }
+        for (int q = 0; q < 9; q++) a.M[q] = Mbuf + (size_t)q * ns;
         for (int d = 0; d < 3; d++) {
             a.L[d] = Lbuf + (size_t)d * ns;
             a.d[d] = dbuf + (size_t)d * ns;
@@ -476,21 +473,18 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
             {
                 // tensor + factors + Laplacian terms are produced in the natural layout (coalesced
                 // stores) and moved to the skewed layout by the LDS-tiled transpose, 24 arrays a launch
-                Span sp(e, FR3D_K_TENSOR, 4.0 * (2 + 21) * nl * C, C, (long long)nl * C);
-                float *nat = e.f32("JAL_nat", nl * 24);
+                Span sp(e, FR3D_K_TENSOR, 4.0 * (2 + 12) * nl * C, C, (long long)nl * C);
+                float *nat = e.f32("JAL_nat", nl * 15);
                 for (int c = 0; c < C; c++) {
-                    // reference order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 -> solver slots (J44 is
-                    // not stored: psi comes from the factors)
-                    float *Jo[10] = {nat + 0 * nl, nat + 1 * nl, nat + 2 * nl, nullptr, nat + 3 * nl,
-                                     nat + 4 * nl, nat + 5 * nl, nat + 6 * nl, nat + 7 * nl, nat + 8 * nl};
+                    // only the square-root factors are needed: the solver rebuilds the tensor from
+                    // them on psi-update iterations and keeps its own frozen 3x3 system in between
+                    float *Jo[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
                     launch_motion_tensor(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
-                                         hx, Jo, nat + 9 * nl, (long long)nl, nullptr);
-                    launch_skew_copy_n(e.st, nat, (long long)nl, Jbuf + (size_t)b * a.vsJ + (size_t)c * 9 * ns,
-                                       (long long)ns, 9, sk);
-                    launch_skew_copy_n(e.st, nat + 9 * nl, (long long)nl,
-                                       Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns, (long long)ns, 12, sk);
+                                         hx, Jo, nat, (long long)nl, nullptr);
+                    launch_skew_copy_n(e.st, nat, (long long)nl, Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns,
+                                       (long long)ns, 12, sk);
                 }
-                float *Ln = nat + 21 * nl;
+                float *Ln = nat + 12 * nl;
                 launch_laplace(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Ln, Ln + nl, Ln + 2 * nl, true);
                 launch_skew_copy_n(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, (long long)ns, 3, sk);
             }
@@ -553,7 +547,7 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
     if (want < 1) want = 1;
     const Level &F = lv.back();
     const Skew sk = make_skew(F.z, F.y, F.x);
-    const double per_vol = (double)sk.total * 4.0 * (9.0 * C + 12.0 * C + C + 6.0);
+    const double per_vol = (double)sk.total * 4.0 * (12.0 * C + 9.0 + 6.0);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         // buffers already held by the engine are reused, so this is conservative
@@ -899,13 +893,13 @@ int fr3d_motion_tensor(const float *f1, const float *f2, int Z, int Y, int X, do
     FR3D_CATCH
 }
 
-int fr3d_level_solve(const float *J, const float *A, const float *weight, const float *uvw, int Z, int Y, int X,
-                     int C, const double *alpha3, int iterations, int update_lag, const double *a_data,
-                     double hx, double hy, double hz, int solver_fp64, float *duvw_out)
+int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int Z, int Y, int X, int C,
+                     const double *alpha3, int iterations, int update_lag, const double *a_data, double hx,
+                     double hy, double hz, int solver_fp64, float *duvw_out)
 {
     FR3D_TRY
     ensure_init();
-    FR3D_CHECK(J && A && weight && uvw && alpha3 && a_data && duvw_out, "NULL pointer");
+    FR3D_CHECK(A && weight && uvw && alpha3 && a_data && duvw_out, "NULL pointer");
     FR3D_CHECK(Z > 0 && Y > 0 && X > 0 && C >= 1 && C <= 4, "bad solver shape");
     FR3D_CHECK(iterations >= 0 && update_lag >= 1, "iterations >= 0 and update_lag >= 1 required");
     Engine &e = g_eng;
@@ -913,14 +907,12 @@ int fr3d_level_solve(const float *J, const float *A, const float *weight, const 
     const Skew sk = make_skew(Z, Y, X);
     const size_t ns = (size_t)sk.total;
     Staged s;
-    const float *dJ = (const float *)s.up(J, n * 9 * C * 4);
     const float *dA = (const float *)s.up(A, n * 12 * C * 4);
     const float *dW = (const float *)s.up(weight, n * C * 4);
     const float *dU = (const float *)s.up(uvw, n * 3 * 4);
-    float *Jsk = (float *)s.alloc(ns * 9 * C * 4);
+    float *Msk = (float *)s.alloc(ns * 9 * 4);
     float *Ask = (float *)s.alloc(ns * 12 * C * 4);
     float *wsk = (float *)s.alloc(ns * C * 4);
-    float *wpsi = (float *)s.alloc(ns * C * 4);
     float *Lb = (float *)s.alloc(ns * 3 * 4);
     float *db = (float *)s.alloc(ns * 3 * 4);
     float *dn = (float *)s.alloc(n * 3 * 4);
@@ -928,12 +920,7 @@ int fr3d_level_solve(const float *J, const float *A, const float *weight, const 
     std::memset(&a, 0, sizeof(a));
     a.sk = sk;
     a.C = C;
-    for (int q = 0; q < 9; q++)
-        for (int c = 0; c < C; c++) {
-            float *dst = Jsk + ((size_t)q * C + c) * ns;
-            launch_skew_copy(e.st, dJ + ((size_t)q * C + c) * n, sk, dst);
-            a.J[q * FR3D_MAX_CHANNELS + c] = dst;
-        }
+    for (int q = 0; q < 9; q++) a.M[q] = Msk + (size_t)q * ns;
     for (int q = 0; q < 12; q++)
         for (int c = 0; c < C; c++) {
             float *dst = Ask + ((size_t)q * C + c) * ns;
@@ -943,7 +930,6 @@ int fr3d_level_solve(const float *J, const float *A, const float *weight, const 
     for (int c = 0; c < C; c++) {
         launch_skew_copy(e.st, dW + (size_t)c * n, sk, wsk + (size_t)c * ns);
         a.weight[c] = wsk + (size_t)c * ns;
-        a.wpsi[c] = wpsi + (size_t)c * ns;
         a.a_data[c] = a_data[c];
     }
     a.ax = alpha3[0] / (hx * hx);

@@ -74,13 +74,13 @@ static inline Skew make_skew(int Z, int Y, int X)
 }
 
 struct SorArgs {
-    // per channel c: J[a*FR3D_MAX_CHANNELS + c], a in 0..8 = J11,J22,J33,J12,J13,J23,J14,J24,J34
-    const float *J[9 * FR3D_MAX_CHANNELS];
+    // frozen per-voxel system of the current psi window: M11,M22,M33,M12,M13,M23,b_u,b_v,b_w
+    // (written on psi-update iterations, read on the others; channels already summed)
+    float *M[9];
     // square-root factors of the motion tensor, A[q*FR3D_MAX_CHANNELS + c], q = 4*k + a
     // (k = x,y,z equation; a = u,v,w,t column): J = sum_k a_k a_k^T.  Read on psi-update iterations.
     const float *A[12 * FR3D_MAX_CHANNELS];
     const float *weight[FR3D_MAX_CHANNELS];
-    float *wpsi[FR3D_MAX_CHANNELS];
     const float *L[3];  // alpha-weighted Laplacian of u,v,w (constant over the iterations)
     float *d[3];        // du,dv,dw, updated in place
     Skew sk;
@@ -91,7 +91,7 @@ struct SorArgs {
     // batch of volumes solved in lock step by the same launches: pointers above are volume 0,
     // volume v adds v*stride elements (weights are shared by all volumes of a batch)
     int nvol;
-    long long vsJ, vsA, vsP, vsL, vsD;
+    long long vsM, vsA, vsL, vsD;
     int dbg;  // measurement-only ablation bits (FR3D_SOR_DBG); 0 in production
 };
 

@@ -10,10 +10,12 @@
 // neighbour states), with S + 2(iterations-1) launches per level instead of iterations*S.
 //
 // Data sits in the skewed layout of fr3d_internal.h, so a wave reads/writes contiguous j-runs
-// and the six neighbours are constant offsets.  Per voxel update the kernel streams
-// 9C tensor entries + C (w*psi) + 3 Laplacian terms + 3 increments and writes 3 increments:
-// 4*(10C+9) algorithmic bytes (76 B for C = 1).  On psi-update iterations (every update_lag-th)
-// it reads the 12C square-root factors + C weights instead of the 9C entries + C (w*psi).
+// and the six neighbours are row-uniform offsets.  The algorithmic traffic of the reference's
+// update is 9C tensor entries + C (w*psi) + 3 Laplacian terms + 3 increments read, 3 written:
+// 4*(10C+9) bytes (76 B for C = 1) -- the figure bench.py prices the kernel against.  The kernel
+// itself streams less: between psi updates the per-voxel 3x3 system (6+3 floats, channels summed)
+// is frozen, so ordinary iterations read 9 + 3 floats and write 3; psi-update iterations (every
+// update_lag-th) read the 12C square-root factors + C weights + 3 L + 3 d and write 9 + 3.
 //
 // Fusions: the Neumann ghost copy set_boundary_3d (:246-259) becomes "a missing neighbour is the
 // voxel's own old value"; the psi_data update (:356-377) is pointwise in the old increment, so it
@@ -67,8 +69,7 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
 
     const size_t c0 = (size_t)((long long)s * plane + (long long)k * Yp + jj);
     const long long d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
-    const size_t oJ = c0 + (size_t)(vol * a.vsJ), oA = c0 + (size_t)(vol * a.vsA), oP = c0 + (size_t)(vol * a.vsP),
-                 oL = c0 + (size_t)(vol * a.vsL);
+    const size_t oM = c0 + (size_t)(vol * a.vsM), oA = c0 + (size_t)(vol * a.vsA), oL = c0 + (size_t)(vol * a.vsL);
     float *const dU = a.d[0] + vol * a.vsD, *const dV = a.d[1] + vol * a.vsD, *const dW = a.d[2] + vol * a.vsD;
     const R du0 = (R)dU[c0], dv0 = (R)dV[c0], dw0 = (R)dW[c0];
 
@@ -96,25 +97,22 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
         sv_z = (hm ? (R)dV[m] : dv0) + (hp ? (R)dV[p] : dv0);
         sw_z = (hm ? (R)dW[m] : dw0) + (hp ? (R)dW[p] : dw0);
     }
-    const R ax = (R)a.ax, ay = (R)a.ay, az = (R)a.az;
-    R num_u = fma_<R>(az, su_z, fma_<R>(ay, su_y, fma_<R>(ax, su_x, (R)a.L[0][oL])));
-    R num_v = fma_<R>(az, sv_z, fma_<R>(ay, sv_y, fma_<R>(ax, sv_x, (R)a.L[1][oL])));
-    R num_w = fma_<R>(az, sw_z, fma_<R>(ay, sw_y, fma_<R>(ax, sw_x, (R)a.L[2][oL])));
-    const R diag = (R)(2.0 * a.ax + 2.0 * a.ay + 2.0 * a.az);
-    R den_u = diag, den_v = diag, den_w = diag;
-
+    // System of this voxel for the current psi window: M = sum_c w_c psi_c J_c (6 entries of the
+    // symmetric 3x3 block) and b = L - sum_c w_c psi_c (J14,J24,J34)_c.  psi is frozen between
+    // psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration
+    // builds them from the factors and stores them, the other iterations just stream the 9 values
+    // -- independent of the channel count.
+    R M11, M22, M33, M12, M13, M23, b_u, b_v, b_w;
     const bool upd = (t % a.update_lag) == 0 && !(a.dbg & 4);
-    R j12[C], j13[C], j23[C], ww[C];
-    R bu = 0, bv = 0, bw = 0;  // sum_c ww*J14, ww*J24, ww*J34
+    if (upd) {
+        M11 = M22 = M33 = M12 = M13 = M23 = (R)0;
+        R bu = 0, bv = 0, bw = 0;
 #pragma unroll
-    for (int c = 0; c < C; c++) {
-        R J11, J22, J33, J12, J13, J23, J14, J24, J34, w;
-        if (upd) {
+        for (int c = 0; c < C; c++) {
             // psi_data update (level_solver_3d.py:356-377) from the increments of iteration t-1.
             // The quadratic form is evaluated as the sum of three squared residuals of the tensor's
             // square-root factors (see k_tensor.hip) -- algebraically the reference's expression,
-            // but stable with fp32 storage -- and the nine tensor entries this iteration needs are
-            // rebuilt from the same factors instead of being read.
+            // but stable with fp32 storage.
             float f[12];
 #pragma unroll
             for (int q = 0; q < 12; q++) f[q] = a.A[q * FR3D_MAX_CHANNELS + c][oA];
@@ -129,62 +127,53 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
                                    fma((double)f[4 * k + 2], w_, (double)f[4 * k + 3])));
                     val = fma(r, r, val);
                 }
-                // fp32 powf (~1 ulp): w*psi is stored in fp32 anyway, and the fp64 pow's ~600-instruction
-                // dependent chain set a ~6 us latency floor on every launch
+                // fp32 powf (~1 ulp): the products below are stored in fp32 anyway, and the fp64
+                // pow's ~600-instruction dependent chain set a ~6 us latency floor on every launch
                 wt *= adc * (double)powf((float)(val + 1e-6), (float)(adc - 1.0));
             }
-            const float wf = (float)wt;
-            a.wpsi[c][oP] = wf;
-            w = (R)wf;
+            const R w = (R)(float)wt;
             const R x0 = (R)f[0], x1 = (R)f[1], x2 = (R)f[2], x3 = (R)f[3];
             const R y0 = (R)f[4], y1 = (R)f[5], y2 = (R)f[6], y3 = (R)f[7];
             const R z0 = (R)f[8], z1 = (R)f[9], z2 = (R)f[10], z3 = (R)f[11];
-            J11 = fma_<R>(z0, z0, fma_<R>(y0, y0, x0 * x0));
-            J22 = fma_<R>(z1, z1, fma_<R>(y1, y1, x1 * x1));
-            J33 = fma_<R>(z2, z2, fma_<R>(y2, y2, x2 * x2));
-            J12 = fma_<R>(z0, z1, fma_<R>(y0, y1, x0 * x1));
-            J13 = fma_<R>(z0, z2, fma_<R>(y0, y2, x0 * x2));
-            J23 = fma_<R>(z1, z2, fma_<R>(y1, y2, x1 * x2));
-            J14 = fma_<R>(z0, z3, fma_<R>(y0, y3, x0 * x3));
-            J24 = fma_<R>(z1, z3, fma_<R>(y1, y3, x1 * x3));
-            J34 = fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3));
-        } else {
-            J11 = (R)a.J[0 * FR3D_MAX_CHANNELS + c][oJ];
-            J22 = (R)a.J[1 * FR3D_MAX_CHANNELS + c][oJ];
-            J33 = (R)a.J[2 * FR3D_MAX_CHANNELS + c][oJ];
-            J12 = (R)a.J[3 * FR3D_MAX_CHANNELS + c][oJ];
-            J13 = (R)a.J[4 * FR3D_MAX_CHANNELS + c][oJ];
-            J23 = (R)a.J[5 * FR3D_MAX_CHANNELS + c][oJ];
-            J14 = (R)a.J[6 * FR3D_MAX_CHANNELS + c][oJ];
-            J24 = (R)a.J[7 * FR3D_MAX_CHANNELS + c][oJ];
-            J34 = (R)a.J[8 * FR3D_MAX_CHANNELS + c][oJ];
-            w = (R)a.wpsi[c][oP];
+            M11 = fma_<R>(w, fma_<R>(z0, z0, fma_<R>(y0, y0, x0 * x0)), M11);
+            M22 = fma_<R>(w, fma_<R>(z1, z1, fma_<R>(y1, y1, x1 * x1)), M22);
+            M33 = fma_<R>(w, fma_<R>(z2, z2, fma_<R>(y2, y2, x2 * x2)), M33);
+            M12 = fma_<R>(w, fma_<R>(z0, z1, fma_<R>(y0, y1, x0 * x1)), M12);
+            M13 = fma_<R>(w, fma_<R>(z0, z2, fma_<R>(y0, y2, x0 * x2)), M13);
+            M23 = fma_<R>(w, fma_<R>(z1, z2, fma_<R>(y1, y2, x1 * x2)), M23);
+            bu = fma_<R>(w, fma_<R>(z0, z3, fma_<R>(y0, y3, x0 * x3)), bu);
+            bv = fma_<R>(w, fma_<R>(z1, z3, fma_<R>(y1, y3, x1 * x3)), bv);
+            bw = fma_<R>(w, fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3)), bw);
         }
-        ww[c] = w;
-        j12[c] = J12; j13[c] = J13; j23[c] = J23;
-        den_u = fma_<R>(w, J11, den_u);
-        den_v = fma_<R>(w, J22, den_v);
-        den_w = fma_<R>(w, J33, den_w);
-        bu = fma_<R>(w, J14, bu);
-        bv = fma_<R>(w, J24, bv);
-        bw = fma_<R>(w, J34, bw);
+        b_u = (R)a.L[0][oL] - bu;
+        b_v = (R)a.L[1][oL] - bv;
+        b_w = (R)a.L[2][oL] - bw;
+        a.M[0][oM] = (float)M11; a.M[1][oM] = (float)M22; a.M[2][oM] = (float)M33;
+        a.M[3][oM] = (float)M12; a.M[4][oM] = (float)M13; a.M[5][oM] = (float)M23;
+        a.M[6][oM] = (float)b_u; a.M[7][oM] = (float)b_v; a.M[8][oM] = (float)b_w;
+        // use the stored (fp32-rounded) values so update and non-update iterations see one system
+        M11 = (R)(float)M11; M22 = (R)(float)M22; M33 = (R)(float)M33;
+        M12 = (R)(float)M12; M13 = (R)(float)M13; M23 = (R)(float)M23;
+        b_u = (R)(float)b_u; b_v = (R)(float)b_v; b_w = (R)(float)b_w;
+    } else {
+        M11 = (R)a.M[0][oM]; M22 = (R)a.M[1][oM]; M33 = (R)a.M[2][oM];
+        M12 = (R)a.M[3][oM]; M13 = (R)a.M[4][oM]; M23 = (R)a.M[5][oM];
+        b_u = (R)a.M[6][oM]; b_v = (R)a.M[7][oM]; b_w = (R)a.M[8][oM];
     }
+    const R ax = (R)a.ax, ay = (R)a.ay, az = (R)a.az;
+    const R num_u = fma_<R>(az, su_z, fma_<R>(ay, su_y, fma_<R>(ax, su_x, b_u)));
+    const R num_v = fma_<R>(az, sv_z, fma_<R>(ay, sv_y, fma_<R>(ax, sv_x, b_v)));
+    const R num_w = fma_<R>(az, sw_z, fma_<R>(ay, sw_y, fma_<R>(ax, sw_x, b_w)));
+    const R diag = (R)(2.0 * a.ax + 2.0 * a.ay + 2.0 * a.az);
+    const R den_u = diag + M11, den_v = diag + M22, den_w = diag + M33;
 
     const R om = (R)SOR_OMEGA, om1 = (R)(1.0 - SOR_OMEGA);
-    // du (uses old dv, dw)
-    R n2 = num_u - bu;
-#pragma unroll
-    for (int c = 0; c < C; c++) n2 -= ww[c] * fma_<R>(j13[c], dw0, j12[c] * dv0);
+    // du (uses old dv, dw), dv (new du, old dw), dw (new du, dv): level_solver_3d.py:503-540
+    R n2 = num_u - fma_<R>(M13, dw0, M12 * dv0);
     const R du1 = fma_<R>(om, (den_u != (R)0 ? n2 / den_u : (R)0), om1 * du0);
-    // dv (uses new du, old dw)
-    n2 = num_v - bv;
-#pragma unroll
-    for (int c = 0; c < C; c++) n2 -= ww[c] * fma_<R>(j23[c], dw0, j12[c] * du1);
+    n2 = num_v - fma_<R>(M23, dw0, M12 * du1);
     const R dv1 = fma_<R>(om, (den_v != (R)0 ? n2 / den_v : (R)0), om1 * dv0);
-    // dw (uses new du, dv)
-    n2 = num_w - bw;
-#pragma unroll
-    for (int c = 0; c < C; c++) n2 -= ww[c] * fma_<R>(j23[c], dv1, j13[c] * du1);
+    n2 = num_w - fma_<R>(M23, dv1, M13 * du1);
     const R dw1 = fma_<R>(om, (den_w != (R)0 ? n2 / den_w : (R)0), om1 * dw0);
 
     dU[c0] = (float)du1;

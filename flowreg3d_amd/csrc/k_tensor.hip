@@ -80,6 +80,7 @@ k_motion_tensor(Img f1, Img f2, double hz, double hy, double hx, float *J11, flo
     double rz = 1.0 / (szn * szn + 1e-6);
 
     size_t o = skewed ? (size_t)sk_index(X, Yp, plane, z, y, x) : (size_t)t;
+    if (J11) {
     J11[o] = (float)(rx * (fxx * fxx) + ry * (fxy * fxy) + rz * (fxz * fxz));
     J22[o] = (float)(rx * (fxy * fxy) + ry * (fyy * fyy) + rz * (fyz * fyz));
     J33[o] = (float)(rx * (fxz * fxz) + ry * (fyz * fyz) + rz * (fzz * fzz));
@@ -90,6 +91,7 @@ k_motion_tensor(Img f1, Img f2, double hz, double hy, double hx, float *J11, flo
     J14[o] = (float)(rx * fxx * fxt + ry * fxy * fyt + rz * fxz * fzt);
     J24[o] = (float)(rx * fxy * fxt + ry * fyy * fyt + rz * fyz * fzt);
     J34[o] = (float)(rx * fxz * fxt + ry * fyz * fyt + rz * fzz * fzt);
+    }
     if (A) {
         // square-root factors: J = sum_k a_k a_k^T with a_k = sqrt(reg_k) * (f_kx, f_ky, f_kz, f_kt).
         // psi_data is evaluated from these (sum of three squared residuals) because the expanded

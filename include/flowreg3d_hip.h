@@ -112,12 +112,12 @@ int fr3d_motion_tensor(const float *f1, const float *f2, int Z, int Y, int X, do
                        double hy, double hx, float *J, float *A);
 
 /* level_solver -> compute_flow_3d (core/level_solver_3d.py:314-546), a_smooth == 1.
- * J: (9,C,Z,Y,X) fp32 interior values, order J11,J22,J33,J12,J13,J23,J14,J24,J34;
- * A: (12,C,Z,Y,X) fp32 factors as above; weight: (C,Z,Y,X) fp32;
- * uvw: (3,Z,Y,X) fp32 interior flow (ghosts are the edge pad of optical_flow_3d.py:88);
- * duvw_out: (3,Z,Y,X) fp32 interior increments. */
-int fr3d_level_solve(const float *J, const float *A, const float *weight, const float *uvw, int Z,
-                     int Y, int X, int C, const double *alpha3, int iterations, int update_lag,
+ * A: (12,C,Z,Y,X) fp32 square-root factors of the motion tensor as fr3d_motion_tensor returns
+ * them (J = sum_k a_k a_k^T; the solver rebuilds the tensor entries from them);
+ * weight: (C,Z,Y,X) fp32; uvw: (3,Z,Y,X) fp32 interior flow (ghosts are the edge pad of
+ * optical_flow_3d.py:88); duvw_out: (3,Z,Y,X) fp32 interior increments. */
+int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int Z, int Y, int X,
+                     int C, const double *alpha3, int iterations, int update_lag,
                      const double *a_data, double hx, double hy, double hz, int solver_fp64,
                      float *duvw_out);
 
