@@ -9,22 +9,49 @@
 
 namespace fr3d {
 
-// axis 2: out (n0,n1,out_len); src rows of length n2
+// axis 2: out (n0,n1,out_len); src rows of length n2.  A thread keeps the P taps of its output
+// column in registers and walks RX_ROWS rows with them (the taps depend on the column only), so the
+// table is read once per RX_ROWS outputs instead of once per output.
+#define RX_ROWS 8
+#define RX_MAXP 16
 __global__ void __launch_bounds__(256)
 k_resize_x(const float *__restrict__ src, int cs, int co, long long rows, int n2, int out_len,
-           const int *__restrict__ idx, const float *__restrict__ wt, int P, float *__restrict__ dst)
+           const int *__restrict__ idx, const float *__restrict__ wt, int P, float *__restrict__ dst,
+           int rpb)
 {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long total = rows * out_len;
-    if (t >= total) return;
-    long long row = t / out_len;
-    int i = (int)(t - row * out_len);
-    const float *r = src + (size_t)row * n2 * cs + co;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= out_len) return;
+    const long long row0 = (long long)blockIdx.y * rpb;
     const int *ii = idx + (size_t)i * P;
     const float *ww = wt + (size_t)i * P;
-    float a = 0.0f;
-    for (int p = 0; p < P; p++) a += r[(size_t)ii[p] * cs] * ww[p];
-    dst[t] = a;
+    if (P <= RX_MAXP) {
+        int tap[RX_MAXP];
+        float w[RX_MAXP];
+#pragma unroll
+        for (int p = 0; p < RX_MAXP; p++) {
+            tap[p] = p < P ? ii[p] * cs : 0;
+            w[p] = p < P ? ww[p] : 0.0f;
+        }
+        for (int q = 0; q < rpb; q++) {
+            const long long row = row0 + q;
+            if (row >= rows) break;
+            const float *r = src + (size_t)row * n2 * cs + co;
+            float a = 0.0f;
+#pragma unroll
+            for (int p = 0; p < RX_MAXP; p++)
+                if (p < P) a += r[tap[p]] * w[p];  // tap order and fp32 mul/add as the reference
+            dst[(size_t)row * out_len + i] = a;
+        }
+    } else {
+        for (int q = 0; q < rpb; q++) {
+            const long long row = row0 + q;
+            if (row >= rows) break;
+            const float *r = src + (size_t)row * n2 * cs + co;
+            float a = 0.0f;
+            for (int p = 0; p < P; p++) a += r[(size_t)ii[p] * cs] * ww[p];
+            dst[(size_t)row * out_len + i] = a;
+        }
+    }
 }
 
 // axis 1 or 0 on planar data: src viewed as (outer, n, inner), dst (outer, out_len, inner)
@@ -55,8 +82,11 @@ void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0
         long long rows = (long long)n0 * n1;
         long long total = rows * out_len;
         if (total == 0) return;
-        hipLaunchKernelGGL(k_resize_x, dim3(cdiv(total, 256)), dim3(256), 0, st, src, cs, co, rows,
-                           n2, out_len, idx, wt, P, dst);
+        (void)total;
+        int rpb = RX_ROWS;
+        if (cdiv(rows, rpb) > 65535) rpb = cdiv(rows, 65535);
+        dim3 grid(cdiv(out_len, 256), cdiv(rows, rpb));
+        hipLaunchKernelGGL(k_resize_x, grid, dim3(256), 0, st, src, cs, co, rows, n2, out_len, idx, wt, P, dst, rpb);
     } else {
         FR3D_CHECK(cs == 1 && co == 0, "resize: y/z passes need planar input");
         long long outer = (axis == 1) ? n0 : 1;
