@@ -31,6 +31,8 @@ WORKLOADS = {
     "cfg2": (256, 256, 256, 4, "256^3 single-channel fp32, 5-level pyramid"),
     "cfg3": (512, 512, 512, 5, "512^3 single-channel fp32, 6-level pyramid"),
 }
+# cfg4 = cfg2 on a 64-timepoint series sharded over N GPUs: `--workload cfg2 --gpus N --steps 8`.
+# cfg5 (512x512x256, two channels) is a parity case (tests/test_gpu_e2e.py, tools/run_cfg5.py), not a bench line.
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -96,7 +98,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=80, help="edge of the CPU-baseline cube")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solver-fp64", action="store_true")
+    ap.add_argument("--solver-fp64", type=int, default=0, choices=(0, 1, 2),
+                    help="0 fp32 storage+update (default), 1 fp64 update arithmetic, 2 fp64 storage (parity-grade)")
     ap.add_argument("--batch", type=int, default=4, help="volumes solved in lock step per GPU (shared launches)")
     args = ap.parse_args()
 
@@ -216,7 +219,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.solver_fp64 < 2 else "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}; iterations=100, update_lag=5, eta=0.8, "
                                    "alpha=0.25, a_data=0.45, a_smooth=1; lexicographic-exact SOR",

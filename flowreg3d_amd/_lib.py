@@ -192,7 +192,7 @@ def make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth,
         raise ValueError(f"at most {MAX_CHANNELS} channels")
     for c in range(n_channels):
         p.a_data[c] = float(ad[c])
-    p.solver_fp64 = 1 if solver_fp64 else 0
+    p.solver_fp64 = int(solver_fp64) if solver_fp64 in (0, 1, 2, True, False) else 1
     return p
 
 

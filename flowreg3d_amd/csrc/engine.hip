@@ -385,11 +385,13 @@ static void build_ref_pyramid(Engine &e, const std::vector<Level> &lv, const flo
 // the solver runs per volume, the SOR launches advance all nb volumes at once (the launch count per
 // level is fixed by the wavefront schedule, so batching multiplies the work per launch and hides
 // the pipeline fill/drain launches that are too small to occupy the chip).
-static void get_displacement_core(Engine &e, const fr3d_params &p, const std::vector<Level> &lv,
-                                  int min_level, const RefPyramid &rp, int nb, const float *const *moving,
-                                  int Z, int Y, int X, int C, const float *uvw_init, float *const *flow_out,
-                                  int reserve_nb = 1)
+template <typename S>
+static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::vector<Level> &lv,
+                                    int min_level, const RefPyramid &rp, int nb, const float *const *moving,
+                                    int Z, int Y, int X, int C, const float *uvw_init, float *const *flow_out,
+                                    int reserve_nb)
 {
+    const std::string sn = sizeof(S) == 8 ? "64" : "";  // separate workspaces per storage type
     FR3D_CHECK(p.a_smooth == 1.0, "a_smooth != 1 is not implemented on the device (SURVEY 8f-3)");
     FR3D_CHECK(nb >= 1 && nb <= 64, "internal: bad batch size");
     const size_t nfull = (size_t)Z * Y * X;
@@ -408,12 +410,12 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
         const Skew sk = make_skew(lz, ly, lx);
         const size_t ns = (size_t)sk.total;
         const size_t nres = (size_t)std::max(nb, reserve_nb);  // slabs reserved (>= nb)
-        float *Mbuf = e.f32("M_sk", ns * 9 * nres);
-        float *Abuf = e.f32("A_sk", ns * 12 * C * nres);
-        float *wsk = e.f32("w_sk", ns * C);
-        float *Lbuf = e.f32("L_sk", ns * 3 * nres);
-        float *dbuf = e.f32("d_sk", ns * 3 * nres);
-        SorArgs a;
+        S *Mbuf = (S *)e.bufs["M_sk" + sn].ensure(ns * 9 * nres * sizeof(S));
+        S *Abuf = (S *)e.bufs["A_sk" + sn].ensure(ns * 12 * C * nres * sizeof(S));
+        S *wsk = (S *)e.bufs["w_sk" + sn].ensure(ns * C * sizeof(S));
+        S *Lbuf = (S *)e.bufs["L_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
+        S *dbuf = (S *)e.bufs["d_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
+        SorArgsT<S> a;
         std::memset(&a, 0, sizeof(a));
         a.sk = sk;
         a.C = C;
@@ -439,8 +441,8 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
         }
         {
             Span sp(e, FR3D_K_OTHER, 0, 0, 0);
-            for (int c = 0; c < C; c++) launch_skew_copy(e.st, rp.wl[li] + (size_t)c * nl, sk, wsk + (size_t)c * ns);
-            FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(float), e.st));
+            launch_skew_copy_n<float, S>(e.st, rp.wl[li], (long long)nl, wsk, (long long)ns, C, sk);
+            FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(S), e.st));
         }
 
         const std::string sfx = flip ? "_a" : "_b";
@@ -474,26 +476,26 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
                 // tensor + factors + Laplacian terms are produced in the natural layout (coalesced
                 // stores) and moved to the skewed layout by the LDS-tiled transpose, 24 arrays a launch
                 Span sp(e, FR3D_K_TENSOR, 4.0 * (2 + 12) * nl * C, C, (long long)nl * C);
-                float *nat = e.f32("JAL_nat", nl * 15);
+                S *nat = (S *)e.bufs["JAL_nat" + sn].ensure(nl * 15 * sizeof(S));
                 for (int c = 0; c < C; c++) {
                     // only the square-root factors are needed: the solver rebuilds the tensor from
                     // them on psi-update iterations and keeps its own frozen 3x3 system in between
                     float *Jo[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-                    launch_motion_tensor(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
-                                         hx, Jo, nat, (long long)nl, nullptr);
-                    launch_skew_copy_n(e.st, nat, (long long)nl, Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns,
-                                       (long long)ns, 12, sk);
+                    launch_motion_tensor<S>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
+                                            hx, Jo, nat, (long long)nl, nullptr);
+                    launch_skew_copy_n<S, S>(e.st, nat, (long long)nl, Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns,
+                                             (long long)ns, 12, sk);
                 }
-                float *Ln = nat + 12 * nl;
-                launch_laplace(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Ln, Ln + nl, Ln + 2 * nl, true);
-                launch_skew_copy_n(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, (long long)ns, 3, sk);
+                S *Ln = nat + 12 * nl;
+                launch_laplace<S>(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Ln, Ln + nl, Ln + 2 * nl, true);
+                launch_skew_copy_n<S, S>(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, (long long)ns, 3, sk);
             }
         }
         a.iterations = p.iterations;
         a.update_lag = p.update_lag;
         {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
-            long long n = launch_sor(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
+            long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
             sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
         }
         // increments back to the natural layout, 5^3 median (:517-526), accumulate (:527-529)
@@ -504,7 +506,9 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
             float **u = &uvw[3 * b];
             {
                 Span sp(e, FR3D_K_OTHER, 0, 0, 0);
-                launch_unskew_copy_n(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
+                // increments leave the solver rounded to fp32: the next level (and the executor) cast to
+                // fp32 anyway (util/resize_util_3D.py:116, sequential_3d.py:150) and the median commutes with it
+                launch_unskew_copy_n<S, float>(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
             }
             if (med) {
                 Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);
@@ -535,9 +539,20 @@ static void get_displacement_core(Engine &e, const fr3d_params &p, const std::ve
     }
 }
 
+static void get_displacement_core(Engine &e, const fr3d_params &p, const std::vector<Level> &lv, int min_level,
+                                  const RefPyramid &rp, int nb, const float *const *moving, int Z, int Y, int X,
+                                  int C, const float *uvw_init, float *const *flow_out, int reserve_nb = 1)
+{
+    if (p.solver_fp64 == 2)
+        get_displacement_core_t<double>(e, p, lv, min_level, rp, nb, moving, Z, Y, X, C, uvw_init, flow_out, reserve_nb);
+    else
+        get_displacement_core_t<float>(e, p, lv, min_level, rp, nb, moving, Z, Y, X, C, uvw_init, flow_out, reserve_nb);
+}
+
 // How many volumes to solve in lock step: FR3D_BATCH (default 4), bounded by free HBM
 // (29 skewed operand arrays per volume and channel set).
 static int g_batch_hint = 0;  // fr3d_set_batch()
+static bool g_fp64_storage = false;
 
 static int pick_batch(int T, const std::vector<Level> &lv, int C)
 {
@@ -547,7 +562,7 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
     if (want < 1) want = 1;
     const Level &F = lv.back();
     const Skew sk = make_skew(F.z, F.y, F.x);
-    const double per_vol = (double)sk.total * 4.0 * (12.0 * C + 9.0 + 6.0);
+    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         // buffers already held by the engine are reused, so this is conservative
@@ -636,6 +651,7 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     // the fixed-reference pyramid and the weight pyramid are time-invariant: build once
     build_ref_pyramid(e, lv, ref_proc, weight, Z, Y, X, C, rp, "pb_");
     const size_t nv = (size_t)Z * Y * X;
+    g_fp64_storage = p->solver_fp64 == 2;
     const int B = T > 0 ? pick_batch(T, lv, C) : 1;
     for (int t0 = 0; t0 < T; t0 += B) {
         const int nb = std::min(B, T - t0);
@@ -886,7 +902,7 @@ int fr3d_motion_tensor(const float *f1, const float *f2, int Z, int Y, int X, do
     float *da = A ? (float *)s.alloc(n * 12 * 4) : nullptr;
     float *Jo[10];
     for (int a = 0; a < 10; a++) Jo[a] = dj + (size_t)a * n;
-    launch_motion_tensor(g_eng.st, d1, d2, Z, Y, X, hz, hy, hx, Jo, da, (long long)n, nullptr);
+    launch_motion_tensor<float>(g_eng.st, d1, d2, Z, Y, X, hz, hy, hx, Jo, da, (long long)n, nullptr);
     FR3D_HIP(hipStreamSynchronize(g_eng.st));
     FR3D_HIP(hipMemcpy(J, dj, n * 10 * 4, hipMemcpyDeviceToHost));
     if (A) FR3D_HIP(hipMemcpy(A, da, n * 12 * 4, hipMemcpyDeviceToHost));
@@ -924,11 +940,11 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     for (int q = 0; q < 12; q++)
         for (int c = 0; c < C; c++) {
             float *dst = Ask + ((size_t)q * C + c) * ns;
-            launch_skew_copy(e.st, dA + ((size_t)q * C + c) * n, sk, dst);
+            launch_skew_copy_n<float, float>(e.st, dA + ((size_t)q * C + c) * n, 0, dst, 0, 1, sk);
             a.A[q * FR3D_MAX_CHANNELS + c] = dst;
         }
     for (int c = 0; c < C; c++) {
-        launch_skew_copy(e.st, dW + (size_t)c * n, sk, wsk + (size_t)c * ns);
+        launch_skew_copy_n<float, float>(e.st, dW + (size_t)c * n, 0, wsk + (size_t)c * ns, 0, 1, sk);
         a.weight[c] = wsk + (size_t)c * ns;
         a.a_data[c] = a_data[c];
     }
@@ -939,12 +955,12 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
         a.L[d] = Lb + (size_t)d * ns;
         a.d[d] = db + (size_t)d * ns;
     }
-    launch_laplace(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lb, Lb + ns, Lb + 2 * ns);
+    launch_laplace<float>(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lb, Lb + ns, Lb + 2 * ns);
     FR3D_HIP(hipMemsetAsync(db, 0, ns * 3 * 4, e.st));
     a.iterations = iterations;
     a.update_lag = update_lag;
-    launch_sor(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
-    for (int d = 0; d < 3; d++) launch_unskew_copy(e.st, db + (size_t)d * ns, sk, dn + (size_t)d * n);
+    launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
+    launch_unskew_copy_n<float, float>(e.st, db, (long long)ns, dn, (long long)n, 3, sk);
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 4, hipMemcpyDeviceToHost));
     FR3D_CATCH

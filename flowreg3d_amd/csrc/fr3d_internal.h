@@ -73,16 +73,20 @@ static inline Skew make_skew(int Z, int Y, int X)
     return k;
 }
 
-struct SorArgs {
+// Solver operands.  S is the storage type of everything the sweep streams: float (default) or
+// double (fr3d_params.solver_fp64 == 2, for configurations where the reference iteration itself is
+// ill-conditioned -- see DESIGN.md section 2).
+template <typename S>
+struct SorArgsT {
     // frozen per-voxel system of the current psi window: M11,M22,M33,M12,M13,M23,b_u,b_v,b_w
     // (written on psi-update iterations, read on the others; channels already summed)
-    float *M[9];
+    S *M[9];
     // square-root factors of the motion tensor, A[q*FR3D_MAX_CHANNELS + c], q = 4*k + a
     // (k = x,y,z equation; a = u,v,w,t column): J = sum_k a_k a_k^T.  Read on psi-update iterations.
-    const float *A[12 * FR3D_MAX_CHANNELS];
-    const float *weight[FR3D_MAX_CHANNELS];
-    const float *L[3];  // alpha-weighted Laplacian of u,v,w (constant over the iterations)
-    float *d[3];        // du,dv,dw, updated in place
+    const S *A[12 * FR3D_MAX_CHANNELS];
+    const S *weight[FR3D_MAX_CHANNELS];
+    const S *L[3];  // alpha-weighted Laplacian of u,v,w (constant over the iterations)
+    S *d[3];        // du,dv,dw, updated in place
     Skew sk;
     double ax, ay, az;  // alpha/h^2
     double a_data[FR3D_MAX_CHANNELS];
@@ -94,6 +98,7 @@ struct SorArgs {
     long long vsM, vsA, vsL, vsD;
     int dbg;  // measurement-only ablation bits (FR3D_SOR_DBG); 0 in production
 };
+using SorArgs = SorArgsT<float>;
 
 // ---- launchers (each enqueues on `st`, no synchronisation) ------------------------------------
 
@@ -120,21 +125,23 @@ void launch_warp_linear(hipStream_t st, const TV *vol, int vcs, int vco, const T
 // K3 motion tensor: f1,f2 planar (Z,Y,X) fp32.  Jout[a] for a = J11,J22,J33,J44,J12,J13,J23,
 // J14,J24,J34; A (nullable): 12 factor arrays a_stride apart; written skewed (sk != nullptr) or
 // natural.
+template <typename TA>
 void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int Z, int Y, int X,
-                          double hz, double hy, double hx, float *const Jout[10], float *A,
+                          double hz, double hy, double hx, float *const Jout[10], TA *A,
                           long long a_stride, const Skew *sk);
 
 // K4-K7 SOR
-void launch_skew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst);
-void launch_unskew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst);
-// narr arrays, src_stride / dst_stride elements apart
-void launch_skew_copy_n(hipStream_t st, const float *src, long long src_stride, float *dst,
+// narr arrays, src_stride / dst_stride elements apart; element types may differ (converted)
+template <typename TS, typename TD>
+void launch_skew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst,
                         long long dst_stride, int narr, const Skew &sk);
-void launch_unskew_copy_n(hipStream_t st, const float *src, long long src_stride, float *dst,
+template <typename TS, typename TD>
+void launch_unskew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst,
                           long long dst_stride, int narr, const Skew &sk);
 // natural = true writes L in the natural (Z,Y,X) layout instead of the skewed one
+template <typename TL>
 void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
-                    double ax, double ay, double az, float *Lu, float *Lv, float *Lw, bool natural = false);
+                    double ax, double ay, double az, TL *Lu, TL *Lv, TL *Lw, bool natural = false);
 // Launch schedule of one level geometry: for every launch tau and every in-flight iteration t the
 // bounding box (in tile units) of the valid part of hyperplane s = tau - 2t, so that only tiles that
 // can hold voxels are dispatched (an all-covering grid spends ~8 us per launch on empty workgroups).
@@ -150,7 +157,8 @@ struct SorSched {
 SorSched build_sor_schedule(const Skew &sk, int iterations);
 void free_sor_schedule(SorSched &s);
 // Runs all `iterations` pipelined hyperplane steps.  Returns the number of kernel launches.
-long long launch_sor(hipStream_t st, const SorArgs &a, bool fp64, const SorSched &sched);
+template <typename S>
+long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorSched &sched);
 
 // K8 median (natural layout)
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);

@@ -38,9 +38,9 @@ template <typename R> __device__ __forceinline__ R fma_(R a, R b, R c);
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
 
-template <typename R, int C>
+template <typename R, typename S, int C>
 __global__ void __launch_bounds__(SOR_BX * SOR_BY)
-k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent)
+k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent)
 {
     const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X, Yp = a.sk.Yp;
     const long long plane = a.sk.plane;
@@ -70,7 +70,7 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
     const size_t c0 = (size_t)((long long)s * plane + (long long)k * Yp + jj);
     const long long d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
     const size_t oM = c0 + (size_t)(vol * a.vsM), oA = c0 + (size_t)(vol * a.vsA), oL = c0 + (size_t)(vol * a.vsL);
-    float *const dU = a.d[0] + vol * a.vsD, *const dV = a.d[1] + vol * a.vsD, *const dW = a.d[2] + vol * a.vsD;
+    S *const dU = a.d[0] + vol * a.vsD, *const dV = a.d[1] + vol * a.vsD, *const dW = a.d[2] + vol * a.vsD;
     const R du0 = (R)dU[c0], dv0 = (R)dV[c0], dw0 = (R)dW[c0];
 
     // neighbour sums; a ghost neighbour holds the voxel's own old value (set_boundary_3d)
@@ -113,7 +113,7 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
             // The quadratic form is evaluated as the sum of three squared residuals of the tensor's
             // square-root factors (see k_tensor.hip) -- algebraically the reference's expression,
             // but stable with fp32 storage.
-            float f[12];
+            S f[12];
 #pragma unroll
             for (int q = 0; q < 12; q++) f[q] = a.A[q * FR3D_MAX_CHANNELS + c][oA];
             double wt = (double)a.weight[c][c0];
@@ -129,9 +129,10 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
                 }
                 // fp32 powf (~1 ulp): the products below are stored in fp32 anyway, and the fp64
                 // pow's ~600-instruction dependent chain set a ~6 us latency floor on every launch
-                wt *= adc * (double)powf((float)(val + 1e-6), (float)(adc - 1.0));
+                if (sizeof(S) == 8) wt *= adc * pow(val + 1e-6, adc - 1.0);  // reference-grade mode
+                else wt *= adc * (double)powf((float)(val + 1e-6), (float)(adc - 1.0));
             }
-            const R w = (R)(float)wt;
+            const R w = (R)(S)wt;
             const R x0 = (R)f[0], x1 = (R)f[1], x2 = (R)f[2], x3 = (R)f[3];
             const R y0 = (R)f[4], y1 = (R)f[5], y2 = (R)f[6], y3 = (R)f[7];
             const R z0 = (R)f[8], z1 = (R)f[9], z2 = (R)f[10], z3 = (R)f[11];
@@ -148,13 +149,13 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
         b_u = (R)a.L[0][oL] - bu;
         b_v = (R)a.L[1][oL] - bv;
         b_w = (R)a.L[2][oL] - bw;
-        a.M[0][oM] = (float)M11; a.M[1][oM] = (float)M22; a.M[2][oM] = (float)M33;
-        a.M[3][oM] = (float)M12; a.M[4][oM] = (float)M13; a.M[5][oM] = (float)M23;
-        a.M[6][oM] = (float)b_u; a.M[7][oM] = (float)b_v; a.M[8][oM] = (float)b_w;
-        // use the stored (fp32-rounded) values so update and non-update iterations see one system
-        M11 = (R)(float)M11; M22 = (R)(float)M22; M33 = (R)(float)M33;
-        M12 = (R)(float)M12; M13 = (R)(float)M13; M23 = (R)(float)M23;
-        b_u = (R)(float)b_u; b_v = (R)(float)b_v; b_w = (R)(float)b_w;
+        a.M[0][oM] = (S)M11; a.M[1][oM] = (S)M22; a.M[2][oM] = (S)M33;
+        a.M[3][oM] = (S)M12; a.M[4][oM] = (S)M13; a.M[5][oM] = (S)M23;
+        a.M[6][oM] = (S)b_u; a.M[7][oM] = (S)b_v; a.M[8][oM] = (S)b_w;
+        // use the stored (rounded) values so update and non-update iterations see one system
+        M11 = (R)(S)M11; M22 = (R)(S)M22; M33 = (R)(S)M33;
+        M12 = (R)(S)M12; M13 = (R)(S)M13; M23 = (R)(S)M23;
+        b_u = (R)(S)b_u; b_v = (R)(S)b_v; b_w = (R)(S)b_w;
     } else {
         M11 = (R)a.M[0][oM]; M22 = (R)a.M[1][oM]; M33 = (R)a.M[2][oM];
         M12 = (R)a.M[3][oM]; M13 = (R)a.M[4][oM]; M23 = (R)a.M[5][oM];
@@ -176,21 +177,21 @@ k_sor_step(const SorArgs a, int tau, int t_lo, int nt, const SorEntry *__restric
     n2 = num_w - fma_<R>(M23, dv1, M13 * du1);
     const R dw1 = fma_<R>(om, (den_w != (R)0 ? n2 / den_w : (R)0), om1 * dw0);
 
-    dU[c0] = (float)du1;
-    dV[c0] = (float)dv1;
-    dW[c0] = (float)dw1;
+    dU[c0] = (S)du1;
+    dV[c0] = (S)dv1;
+    dW[c0] = (S)dw1;
 }
 
-template <typename R>
-static void launch_step(hipStream_t st, const SorArgs &a, int tau, int t_lo, int nt, int ntiles,
+template <typename R, typename S>
+static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo, int nt, int ntiles,
                         const SorEntry *ent)
 {
     dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, SOR_BY);
     switch (a.C) {
-        case 1: hipLaunchKernelGGL((k_sor_step<R, 1>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
-        case 2: hipLaunchKernelGGL((k_sor_step<R, 2>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
-        case 3: hipLaunchKernelGGL((k_sor_step<R, 3>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
-        case 4: hipLaunchKernelGGL((k_sor_step<R, 4>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
+        case 1: hipLaunchKernelGGL((k_sor_step<R, S, 1>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
+        case 2: hipLaunchKernelGGL((k_sor_step<R, S, 2>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
+        case 3: hipLaunchKernelGGL((k_sor_step<R, S, 3>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
+        case 4: hipLaunchKernelGGL((k_sor_step<R, S, 4>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
         default: throw Error("SOR kernel is instantiated for 1..4 channels");
     }
 }
@@ -253,21 +254,24 @@ void free_sor_schedule(SorSched &s)
     s.entries = nullptr;
 }
 
-long long launch_sor(hipStream_t st, const SorArgs &a_in, bool fp64, const SorSched &sc)
+template <typename S>
+long long launch_sor(hipStream_t st, const SorArgsT<S> &a_in, bool fp64, const SorSched &sc)
 {
-    SorArgs a = a_in;
+    SorArgsT<S> a = a_in;
     static const char *dbg_env = getenv("FR3D_SOR_DBG");
     a.dbg = dbg_env ? atoi(dbg_env) : 0;
     long long launches = 0;
     for (size_t l = 0; l < sc.tau.size(); l++) {
         if (sc.ntiles[l] <= 0) continue;
         const SorEntry *ent = sc.entries + sc.first[l];
-        if (fp64) launch_step<double>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent);
-        else launch_step<float>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent);
+        if (fp64 || sizeof(S) == 8) launch_step<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent);
+        else launch_step<float, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent);
         launches++;
     }
     return launches;
 }
+template long long launch_sor<float>(hipStream_t, const SorArgsT<float> &, bool, const SorSched &);
+template long long launch_sor<double>(hipStream_t, const SorArgsT<double> &, bool, const SorSched &);
 
 // ---- layout conversion and the iteration-invariant stencil part -------------------------------
 
@@ -276,11 +280,12 @@ long long launch_sor(hipStream_t st, const SorArgs &a_in, bool fp64, const SorSc
 // along the tile's anti-diagonals (x+y constant => same hyperplane and row, j contiguous), so both
 // sides are coalesced.  A direct scatter costs ~8x write amplification (4-B writes, 128-B lines).
 #define SKT 64
+template <typename TS, typename TD>
 __global__ void __launch_bounds__(256)
-k_skew_tiled(const float *__restrict__ src, long long src_stride, float *__restrict__ dst,
+k_skew_tiled(const TS *__restrict__ src, long long src_stride, TD *__restrict__ dst,
              long long dst_stride, int Z, int Y, int X, int Yp, long long plane, int to_skew)
 {
-    __shared__ float tile[SKT][SKT + 2];
+    __shared__ TD tile[SKT][SKT + 2];
     const int txn = (X + SKT - 1) / SKT;
     const int x0 = (blockIdx.x % txn) * SKT, y0 = (blockIdx.x / txn) * SKT;
     const int z = blockIdx.y;
@@ -290,7 +295,7 @@ k_skew_tiled(const float *__restrict__ src, long long src_stride, float *__restr
     if (to_skew) {
         for (int row = wave; row < SKT; row += 4) {
             const int y = y0 + row, x = x0 + lane;
-            if (y < Y && x < X) tile[row][lane] = src[((size_t)z * Y + y) * X + x];
+            if (y < Y && x < X) tile[row][lane] = (TD)src[((size_t)z * Y + y) * X + x];
         }
         __syncthreads();
         for (int d = wave; d < 2 * SKT - 1; d += 4) {
@@ -302,7 +307,7 @@ k_skew_tiled(const float *__restrict__ src, long long src_stride, float *__restr
         for (int d = wave; d < 2 * SKT - 1; d += 4) {
             const int ly = lane, lx = d - lane;
             const int y = y0 + ly, x = x0 + lx;
-            if (lx >= 0 && lx < SKT && y < Y && x < X) tile[ly][lx] = src[(size_t)sk_index(X, Yp, plane, z, y, x)];
+            if (lx >= 0 && lx < SKT && y < Y && x < X) tile[ly][lx] = (TD)src[(size_t)sk_index(X, Yp, plane, z, y, x)];
         }
         __syncthreads();
         for (int row = wave; row < SKT; row += 4) {
@@ -312,43 +317,42 @@ k_skew_tiled(const float *__restrict__ src, long long src_stride, float *__restr
     }
 }
 
-static void launch_skew_tiled(hipStream_t st, const float *src, long long src_stride, float *dst,
+template <typename TS, typename TD>
+static void launch_skew_tiled(hipStream_t st, const TS *src, long long src_stride, TD *dst,
                               long long dst_stride, int narr, const Skew &sk, int to_skew)
 {
     if (narr <= 0) return;
     dim3 grid(cdiv(sk.X, SKT) * cdiv(sk.Y, SKT), sk.Z, narr);
-    hipLaunchKernelGGL(k_skew_tiled, grid, dim3(256), 0, st, src, src_stride, dst, dst_stride, sk.Z, sk.Y,
-                       sk.X, sk.Yp, sk.plane, to_skew);
+    hipLaunchKernelGGL((k_skew_tiled<TS, TD>), grid, dim3(256), 0, st, src, src_stride, dst, dst_stride, sk.Z,
+                       sk.Y, sk.X, sk.Yp, sk.plane, to_skew);
 }
 
-void launch_skew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst)
+template <typename TS, typename TD>
+void launch_skew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst, long long dst_stride,
+                        int narr, const Skew &sk)
 {
-    launch_skew_tiled(st, src, 0, dst, 0, 1, sk, 1);
+    launch_skew_tiled<TS, TD>(st, src, src_stride, dst, dst_stride, narr, sk, 1);
 }
 
-void launch_unskew_copy(hipStream_t st, const float *src, const Skew &sk, float *dst)
+template <typename TS, typename TD>
+void launch_unskew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst, long long dst_stride,
+                          int narr, const Skew &sk)
 {
-    launch_skew_tiled(st, src, 0, dst, 0, 1, sk, 0);
+    launch_skew_tiled<TS, TD>(st, src, src_stride, dst, dst_stride, narr, sk, 0);
 }
-
-void launch_skew_copy_n(hipStream_t st, const float *src, long long src_stride, float *dst,
-                        long long dst_stride, int narr, const Skew &sk)
-{
-    launch_skew_tiled(st, src, src_stride, dst, dst_stride, narr, sk, 1);
-}
-
-void launch_unskew_copy_n(hipStream_t st, const float *src, long long src_stride, float *dst,
-                          long long dst_stride, int narr, const Skew &sk)
-{
-    launch_skew_tiled(st, src, src_stride, dst, dst_stride, narr, sk, 0);
-}
+template void launch_skew_copy_n<float, float>(hipStream_t, const float *, long long, float *, long long, int, const Skew &);
+template void launch_skew_copy_n<float, double>(hipStream_t, const float *, long long, double *, long long, int, const Skew &);
+template void launch_skew_copy_n<double, double>(hipStream_t, const double *, long long, double *, long long, int, const Skew &);
+template void launch_unskew_copy_n<float, float>(hipStream_t, const float *, long long, float *, long long, int, const Skew &);
+template void launch_unskew_copy_n<double, float>(hipStream_t, const double *, long long, float *, long long, int, const Skew &);
 
 // L = ax*(u_ip + u_im - 2u) + ay*(...) + az*(...) with edge-padded u (add_boundary,
 // core/optical_flow_3d.py:88), evaluated in fp64 from the fp32-exact level flow.
+template <typename TL>
 __global__ void __launch_bounds__(256)
 k_laplace(const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w,
           int Z, int Y, int X, int Yp, long long plane, double ax, double ay, double az,
-          float *__restrict__ Lu, float *__restrict__ Lv, float *__restrict__ Lw)
+          TL *__restrict__ Lu, TL *__restrict__ Lv, TL *__restrict__ Lw)
 {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)Z * Y * X;
@@ -363,7 +367,7 @@ k_laplace(const float *__restrict__ u, const float *__restrict__ v, const float 
     const long long zm = z > 0 ? -sz : 0, zp = z < Z - 1 ? sz : 0;
     size_t o = plane ? (size_t)sk_index(X, Yp, plane, z, y, x) : (size_t)t;
     const float *f[3] = {u, v, w};
-    float *L[3] = {Lu, Lv, Lw};
+    TL *L[3] = {Lu, Lv, Lw};
 #pragma unroll
     for (int d = 0; d < 3; d++) {
         const float *q = f[d] + t;
@@ -371,16 +375,22 @@ k_laplace(const float *__restrict__ u, const float *__restrict__ v, const float 
         double acc = ax * ((double)q[xp] + (double)q[xm] - 2.0 * c);
         acc += ay * ((double)q[yp] + (double)q[ym] - 2.0 * c);
         acc += az * ((double)q[zp] + (double)q[zm] - 2.0 * c);
-        L[d][o] = (float)acc;
+        L[d][o] = (TL)acc;
     }
 }
 
+template <typename TL>
 void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
-                    double ax, double ay, double az, float *Lu, float *Lv, float *Lw, bool natural)
+                    double ax, double ay, double az, TL *Lu, TL *Lv, TL *Lw, bool natural)
 {
     long long total = (long long)sk.Z * sk.Y * sk.X;
-    hipLaunchKernelGGL(k_laplace, dim3(cdiv(total, 256)), dim3(256), 0, st, u, v, w, sk.Z, sk.Y,
+    hipLaunchKernelGGL(k_laplace<TL>, dim3(cdiv(total, 256)), dim3(256), 0, st, u, v, w, sk.Z, sk.Y,
                        sk.X, sk.Yp, natural ? 0LL : sk.plane, ax, ay, az, Lu, Lv, Lw);
 }
+
+template void launch_laplace<float>(hipStream_t, const float *, const float *, const float *, const Skew &, double,
+                                    double, double, float *, float *, float *, bool);
+template void launch_laplace<double>(hipStream_t, const float *, const float *, const float *, const Skew &, double,
+                                     double, double, double *, double *, double *, bool);
 
 }  // namespace fr3d

@@ -23,10 +23,11 @@ struct Img {
 
 __device__ __forceinline__ int cl(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
+template <typename TA>
 __global__ void __launch_bounds__(256)
 k_motion_tensor(Img f1, Img f2, double hz, double hy, double hx, float *J11, float *J22,
                 float *J33, float *J44, float *J12, float *J13, float *J23, float *J14, float *J24,
-                float *J34, float *A, long long a_stride, int skewed, int Yp, long long plane)
+                float *J34, TA *A, long long a_stride, int skewed, int Yp, long long plane)
 {
     const int Z = f1.Z, Y = f1.Y, X = f1.X;
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -97,30 +98,36 @@ k_motion_tensor(Img f1, Img f2, double hz, double hy, double hx, float *J11, flo
         // psi_data is evaluated from these (sum of three squared residuals) because the expanded
         // quadratic form cancels catastrophically once J is rounded to fp32 (numerics).
         const double qx = sqrt(rx), qy = sqrt(ry), qz = sqrt(rz);
-        A[0 * a_stride + o] = (float)(qx * fxx);
-        A[1 * a_stride + o] = (float)(qx * fxy);
-        A[2 * a_stride + o] = (float)(qx * fxz);
-        A[3 * a_stride + o] = (float)(qx * fxt);
-        A[4 * a_stride + o] = (float)(qy * fxy);
-        A[5 * a_stride + o] = (float)(qy * fyy);
-        A[6 * a_stride + o] = (float)(qy * fyz);
-        A[7 * a_stride + o] = (float)(qy * fyt);
-        A[8 * a_stride + o] = (float)(qz * fxz);
-        A[9 * a_stride + o] = (float)(qz * fyz);
-        A[10 * a_stride + o] = (float)(qz * fzz);
-        A[11 * a_stride + o] = (float)(qz * fzt);
+        A[0 * a_stride + o] = (TA)(qx * fxx);
+        A[1 * a_stride + o] = (TA)(qx * fxy);
+        A[2 * a_stride + o] = (TA)(qx * fxz);
+        A[3 * a_stride + o] = (TA)(qx * fxt);
+        A[4 * a_stride + o] = (TA)(qy * fxy);
+        A[5 * a_stride + o] = (TA)(qy * fyy);
+        A[6 * a_stride + o] = (TA)(qy * fyz);
+        A[7 * a_stride + o] = (TA)(qy * fyt);
+        A[8 * a_stride + o] = (TA)(qz * fxz);
+        A[9 * a_stride + o] = (TA)(qz * fyz);
+        A[10 * a_stride + o] = (TA)(qz * fzz);
+        A[11 * a_stride + o] = (TA)(qz * fzt);
     }
 }
 
+template <typename TA>
 void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int Z, int Y, int X,
-                          double hz, double hy, double hx, float *const J[10], float *A,
+                          double hz, double hy, double hx, float *const J[10], TA *A,
                           long long a_stride, const Skew *sk)
 {
     long long total = (long long)Z * Y * X;
     Img a{f1, Z, Y, X}, b{f2, Z, Y, X};
-    hipLaunchKernelGGL(k_motion_tensor, dim3(cdiv(total, 256)), dim3(256), 0, st, a, b, hz, hy, hx,
+    hipLaunchKernelGGL(k_motion_tensor<TA>, dim3(cdiv(total, 256)), dim3(256), 0, st, a, b, hz, hy, hx,
                        J[0], J[1], J[2], J[3], J[4], J[5], J[6], J[7], J[8], J[9], A, a_stride, sk ? 1 : 0,
                        sk ? sk->Yp : 0, sk ? sk->plane : 0LL);
 }
+
+template void launch_motion_tensor<float>(hipStream_t, const float *, const float *, int, int, int, double, double,
+                                          double, float *const[10], float *, long long, const Skew *);
+template void launch_motion_tensor<double>(hipStream_t, const float *, const float *, int, int, int, double, double,
+                                           double, float *const[10], double *, long long, const Skew *);
 
 }  // namespace fr3d

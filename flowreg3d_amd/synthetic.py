@@ -41,6 +41,27 @@ def flow_gt(shape, translation=(1.7, -1.1, 0.6), rot_deg=1.5, scale=1.0):
     return f
 
 
+def flow_expansion_rotation(shape, expansion=(0.010, 0.008, 0.006), rot_deg=(2.0, 2.0, 2.0), scale=1.0):
+    """(Z,Y,X,3) float32 [dx,dy,dz]: anisotropic expansion about the centre ("injection/recoil"
+    stand-in, cf. Expansion3DFlowAugmentor, motion_generation/motion_generators.py:236-301) plus small
+    rotations about all three axes (Rotational3DFlowAugmentor :69-152), closed form."""
+    Z, Y, X = shape
+    zz, yy, xx = np.meshgrid(np.arange(Z, dtype=np.float64), np.arange(Y, dtype=np.float64),
+                             np.arange(X, dtype=np.float64), indexing="ij", sparse=True)
+    cz, cy, cx = (Z - 1) / 2.0, (Y - 1) / 2.0, (X - 1) / 2.0
+    px, py, pz = xx - cx, yy - cy, zz - cz
+    ax, ay, az = (np.deg2rad(a * scale) for a in rot_deg)  # about x, y, z
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    R = Rz @ Ry @ Rx - np.eye(3)
+    f = np.empty((Z, Y, X, 3), np.float32)
+    for d in range(3):
+        f[..., d] = (R[d, 0] * px + R[d, 1] * py + R[d, 2] * pz
+                     + scale * expansion[d] * (px, py, pz)[d]).astype(np.float32)
+    return f
+
+
 def backward_warp(vol, flow, order=3):
     """vol sampled at x + flow (same convention as imregister_wrapper)."""
     Z, Y, X = vol.shape
@@ -49,12 +70,12 @@ def backward_warp(vol, flow, order=3):
     return ndimage.map_coordinates(vol.astype(np.float64), coords, order=order, mode="nearest").astype(np.float32)
 
 
-def make_pair(shape, seed=1234, channels=1, scale=1.0, cheap=False):
+def make_pair(shape, seed=1234, channels=1, scale=1.0, cheap=False, motion="rigid"):
     """-> fixed, moving (Z,Y,X[,C]) float32 in [0,1] and the ground-truth flow (Z,Y,X,3).
 
     moving(x) = fixed(x - flow), so get_displacement(fixed, moving) ~ flow.  ``cheap`` uses
     linear interpolation (fast for 256^3/512^3 bench volumes)."""
-    gt = flow_gt(shape, scale=scale)
+    gt = flow_gt(shape, scale=scale) if motion == "rigid" else flow_expansion_rotation(shape, scale=scale)
     fs, ms = [], []
     for c in range(channels):
         f = texture(shape, seed + c)

@@ -44,7 +44,10 @@ typedef struct fr3d_params {
     double a_smooth;                   /* only 1.0 is implemented on the device */
     double a_data[FR3D_MAX_CHANNELS];  /* per channel */
     int solver_fp64;                   /* 0: fp32 storage + fp32 update arithmetic (default);
-                                          1: fp32 storage, fp64 update arithmetic */
+                                          1: fp32 storage, fp64 update arithmetic;
+                                          2: fp64 storage and arithmetic in the solver (2x the
+                                             bytes; for configurations where the reference's own
+                                             iteration is ill-conditioned) */
     int reserved[7];
 } fr3d_params;
 

@@ -89,7 +89,11 @@ def test_schedule(oracle):
 
 @pytest.mark.parametrize("name,tol_mean,tol_max", [
     ("e2e_small", 2e-6, 5e-5), ("e2e_asmooth", 1e-7, 1e-6), ("e2e_c2", 4e-6, 1e-4),
-    ("e2e_minlevel", 2e-6, 1e-4), ("e2e_cfg1", 8e-6, 1e-3)])
+    ("e2e_minlevel", 2e-6, 1e-4), ("e2e_cfg1", 8e-6, 1e-3),
+    # two channels + update_lag 5: the reference iteration is ill-conditioned (a 1e-15 relative
+    # difference in SciPy's spline coefficients is the only non-bit-exact stage and already moves
+    # the flow by 3e-5 mean / 7e-3 max) -- this fixture documents the reference's own reproducibility
+    ("e2e_cfg5like", 6e-5, 2e-2)])
 def test_get_displacement_vs_reference(oracle, name, tol_mean, tol_max):
     """Whole pipeline.  Every stage above is bit-exact except SciPy's prefilter (1e-15 relative);
     an fp32 rounding of a warped voxel that flips on that moves the flow by ~1e-6, hence a
