@@ -20,9 +20,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FR3D_LIB") or os.path.join(_HERE, "lib", "libflowreg3d_hip.so")  # FR3D_LIB: A/B builds
 MAX_CHANNELS = 8
-F32, F64 = 0, 1
+F32, F64, U8, U16, I16 = 0, 1, 2, 3, 4
 
-K_NAMES = ("sor", "warp", "prefilter", "tensor", "resize", "median", "other")
+K_NAMES = ("sor", "warp", "prefilter", "tensor", "resize", "median", "other", "preproc")
 
 
 class Params(C.Structure):
@@ -70,6 +70,10 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, _vp, _vp, PROGRESS_FN, _vp]),
     "fr3d_process_batch_dev": (C.c_int, [C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, _vp, _vp, PROGRESS_FN, _vp]),
+    "fr3d_preprocess": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double,
+                                  _vp, C.c_int]),
+    "fr3d_preprocess_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                      C.c_double, _vp, C.c_int]),
     "fr3d_resize3d": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_motion_tensor": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "fr3d_level_solve": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,

@@ -676,6 +676,110 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     FR3D_HIP(hipStreamSynchronize(e.st));
 }
 
+// ---- f-1 preprocessing ----------------------------------------------------------------------------
+// scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, int(truncate*sigma+0.5)), fp64
+static std::vector<double> gaussian_kernel(double sigma, double truncate, int &radius)
+{
+    radius = (int)(truncate * sigma + 0.5);
+    const int n = 2 * radius + 1;
+    std::vector<double> w(n);
+    const double sigma2 = sigma * sigma;
+    for (int i = 0; i < n; i++) {
+        const double x = (double)(i - radius);
+        w[i] = std::exp(-0.5 / sigma2 * (x * x));
+    }
+    double s;
+    if (n < 8) {
+        s = 0.0;
+        for (int i = 0; i < n; i++) s += w[i];
+    } else {  // numpy pairwise add.reduce (n <= 128 in practice)
+        double r[8];
+        int i;
+        for (i = 0; i < 8; i++) r[i] = w[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += w[i + j];
+        s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) s += w[i];
+    }
+    for (auto &v : w) v = v / s;
+    return w;
+}
+
+template <typename TIN>
+static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int X, int C, const double *nmin,
+                         const double *nden, const double *sigma, double truncate, void *out, int out_dtype)
+{
+    const long long n = (long long)T * Z * Y * X;
+    double *bufA = e.f64("pp_a", (size_t)n);
+    double *bufB = e.f64("pp_b", (size_t)n);
+    Span sp(e, FR3D_K_PREPROC, 0, 0, 0);
+    for (int c = 0; c < C; c++) {
+        const double *sg = sigma + 4 * c;            // sx, sy, sz, st
+        const double ax_sigma[4] = {sg[3], sg[2], sg[1], sg[0]};  // array axes T, Z, Y, X
+        const double *cur = nullptr;                 // nullptr: still reading the caller's frames
+        double *dst = bufA;
+        int passes = 0;
+        for (int axis = 0; axis < 4; axis++) {
+            if (!(ax_sigma[axis] > 1e-15)) continue; // scipy skips these axes
+            int radius;
+            std::vector<double> w = gaussian_kernel(ax_sigma[axis], truncate, radius);
+            if (radius == 0 && cur) continue;        // kernel [1.0]: x*1.0 is x, nothing to do
+            double *dw = (double *)e.bufs["pp_w" + std::to_string(axis)].ensure(w.size() * sizeof(double));
+            FR3D_HIP(hipMemcpyAsync(dw, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, e.st));
+            FR3D_HIP(hipStreamSynchronize(e.st));    // w is a host temporary
+            if (!cur) launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, axis, dw, radius, dst);
+            else launch_gauss_pass<double>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, axis, dw, radius, dst);
+            cur = dst;
+            dst = (dst == bufA) ? bufB : bufA;
+            passes++;
+        }
+        if (!cur) {  // no filtering at all: normalisation only (a radius-0 pass)
+            const double one = 1.0;
+            double *dw = (double *)e.bufs["pp_w0"].ensure(sizeof(double));
+            FR3D_HIP(hipMemcpyAsync(dw, &one, sizeof(double), hipMemcpyHostToDevice, e.st));
+            FR3D_HIP(hipStreamSynchronize(e.st));
+            launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, 3, dw, 0, dst);
+            cur = dst;
+            passes++;
+        }
+        if (out_dtype == FR3D_F64) launch_store_channel<double>(e.st, cur, n, C, c, (double *)out);
+        else launch_store_channel<float>(e.st, cur, n, C, c, (float *)out);
+        sp.add(8.0 * (double)n * 2.0 * passes, passes + 1, n);
+    }
+}
+
+static size_t dtype_size(int dt)
+{
+    switch (dt) {
+        case FR3D_F32: return 4;
+        case FR3D_F64: return 8;
+        case FR3D_U8: return 1;
+        case FR3D_U16: case FR3D_I16: return 2;
+        default: throw Error("unknown dtype code");
+    }
+}
+
+static void preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *nmin,
+                           const double *nden, const double *sigma, double truncate, void *out, int out_dtype)
+{
+    ensure_init();
+    FR3D_CHECK(frames && nmin && nden && sigma && out, "NULL pointer");
+    FR3D_CHECK(T >= 0 && Z >= 1 && Y >= 1 && X >= 1 && C >= 1 && C <= FR3D_MAX_CHANNELS, "bad preprocess shape");
+    FR3D_CHECK(out_dtype == FR3D_F32 || out_dtype == FR3D_F64, "out_dtype must be FR3D_F32 or FR3D_F64");
+    FR3D_CHECK(truncate > 0.0, "truncate must be positive");
+    for (int c = 0; c < C; c++) FR3D_CHECK(nden[c] != 0.0, "normalisation denominator is zero");
+    Engine &e = g_eng;
+    switch (dtype) {
+        case FR3D_F32: preprocess_t<float>(e, (const float *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
+        case FR3D_F64: preprocess_t<double>(e, (const double *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
+        case FR3D_U8: preprocess_t<unsigned char>(e, (const unsigned char *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
+        case FR3D_U16: preprocess_t<unsigned short>(e, (const unsigned short *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
+        case FR3D_I16: preprocess_t<short>(e, (const short *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
+        default: throw Error("unknown dtype code");
+    }
+    FR3D_HIP(hipStreamSynchronize(e.st));
+}
+
 // host staging helper
 struct Staged {
     std::vector<void *> ptrs;
@@ -869,6 +973,31 @@ int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const floa
     process_batch_dev(p, dbp, dbr, drp, drr, dwi, dwt, T, Z, Y, X, C, order, dfl, dre, progress, user);
     FR3D_HIP(hipMemcpy(flows_out, dfl, nv * 3 * 4 * (size_t)T, hipMemcpyDeviceToHost));
     FR3D_HIP(hipMemcpy(registered_out, dre, nv * C * 4 * (size_t)T, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *norm_min,
+                        const double *norm_den, const double *sigma, double truncate, void *out, int out_dtype)
+{
+    FR3D_TRY
+    preprocess_dev(frames, dtype, T, Z, Y, X, C, norm_min, norm_den, sigma, truncate, out, out_dtype);
+    FR3D_CATCH
+}
+
+int fr3d_preprocess(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *norm_min,
+                    const double *norm_den, const double *sigma, double truncate, void *out, int out_dtype)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(frames && out, "NULL pointer");
+    FR3D_CHECK(T >= 0 && Z >= 1 && Y >= 1 && X >= 1 && C >= 1, "bad preprocess shape");
+    FR3D_CHECK(out_dtype == FR3D_F32 || out_dtype == FR3D_F64, "out_dtype must be FR3D_F32 or FR3D_F64");
+    const size_t n = (size_t)T * Z * Y * X * C;
+    Staged s;
+    const void *din = s.up(frames, n * dtype_size(dtype));
+    void *dout = s.alloc(n * dtype_size(out_dtype));
+    preprocess_dev(din, dtype, T, Z, Y, X, C, norm_min, norm_den, sigma, truncate, dout, out_dtype);
+    FR3D_HIP(hipMemcpy(out, dout, n * dtype_size(out_dtype), hipMemcpyDeviceToHost));
     FR3D_CATCH
 }
 

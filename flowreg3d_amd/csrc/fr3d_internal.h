@@ -163,6 +163,13 @@ long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorS
 // K8 median (natural layout)
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);
 
+// f-1 preprocessing (k_preproc.hip)
+template <typename TIN>
+void launch_gauss_pass(hipStream_t st, const TIN *in, int cs, int co, double nmin, double nden, int T, int Z,
+                       int Y, int X, int axis, const double *w, int radius, double *out);
+template <typename TOUT>
+void launch_store_channel(hipStream_t st, const double *in, long long n, int C, int c, TOUT *out);
+
 // K9 pointwise helpers
 void launch_axpy(hipStream_t st, float *y, const float *x, long long n);  // y += x
 void launch_fill(hipStream_t st, float *y, float v, long long n);

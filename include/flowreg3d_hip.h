@@ -30,6 +30,9 @@ extern "C" {
 /* element types of caller buffers */
 #define FR3D_F32 0
 #define FR3D_F64 1
+#define FR3D_U8 2
+#define FR3D_U16 3
+#define FR3D_I16 4
 
 /* Solver parameters = keyword arguments of get_displacement
  * (core/optical_flow_3d.py:319-333) as the executors pass them in `flow_params`
@@ -102,6 +105,21 @@ int fr3d_process_batch_dev(const fr3d_params *p, const float *batch_proc, const 
                            float *flows_out, float *registered_out, fr3d_progress_fn progress,
                            void *user);
 
+/* Preprocessing in front of the flow path (SURVEY section 8 f-1;
+ * motion_correction/compensate_recording_3D.py:229-254): per channel c
+ *   out = gaussian_filter((frames - norm_min[c]) / norm_den[c], sigma, mode="reflect", truncate)
+ * (util/image_processing_3D.py:12-162).  frames: (T,Z,Y,X,C) of `dtype`; sigma: (C,4) =
+ * [sx,sy,sz,st] per channel (st filters across the T volumes of the batch, as the reference's 4-D
+ * filter does; axes with sigma <= 1e-15 are skipped); out: (T,Z,Y,X,C) of out_dtype (F32|F64).
+ * norm_min/norm_den are the caller's normalisation constants (min and max-min(+eps) of the
+ * reference volume for "together", per channel for "separate"; 0 and 1 for no normalisation). */
+int fr3d_preprocess(const void *frames, int dtype, int T, int Z, int Y, int X, int C,
+                    const double *norm_min, const double *norm_den, const double *sigma,
+                    double truncate, void *out, int out_dtype);
+int fr3d_preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C,
+                        const double *norm_min, const double *norm_den, const double *sigma,
+                        double truncate, void *out, int out_dtype);
+
 /* ---- kernel-level entry points (stage parity tests; host pointers) ---------------------- */
 
 /* imresize_fused_gauss_cubic3D (util/resize_util_3D.py:114-156), one fp32 channel. */
@@ -150,7 +168,8 @@ int fr3d_sync(void);
 #define FR3D_K_RESIZE 4
 #define FR3D_K_MEDIAN 5
 #define FR3D_K_OTHER 6
-#define FR3D_K_COUNT 7
+#define FR3D_K_PREPROC 7
+#define FR3D_K_COUNT 8
 typedef struct fr3d_kernel_stat {
     double ms;              /* summed event-to-event time */
     double algo_bytes;      /* algorithmic bytes moved (per-kernel definition) */

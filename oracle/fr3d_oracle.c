@@ -948,3 +948,95 @@ int fr3d_oracle_get_displacement(const double *fixed, const double *moving, int 
     for (int d = 0; d < 3; d++) free(init[d]);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* f-1  preprocessing: normalize + Gaussian filter      util/image_processing_3D.py:12-162      */
+/*      (scipy.ndimage.gaussian_filter(mode="reflect", truncate=4.0), fp64)                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* numpy's float64 pairwise add.reduce for n <= 128 (same blocking as the float32 one above) */
+static double np_sum_f64(const double *a, int n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r[8];
+    int i;
+    for (i = 0; i < 8; i++) r[i] = a[i];
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+/* scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius); w has 2*radius+1 entries */
+int fr3d_oracle_gaussian_kernel(double sigma, double truncate, double *w, int max_len)
+{
+    int radius = (int)(truncate * sigma + 0.5);
+    int n = 2 * radius + 1;
+    if (!w) return radius;
+    if (n > max_len) return -1;
+    double sigma2 = sigma * sigma;
+    for (int i = 0; i < n; i++) {
+        double x = (double)(i - radius);
+        w[i] = exp(-0.5 / sigma2 * (x * x));
+    }
+    double s = n <= 128 ? np_sum_f64(w, n) : 0.0;
+    if (n > 128) for (int i = 0; i < n; i++) s += w[i];
+    for (int i = 0; i < n; i++) w[i] = w[i] / s;
+    return radius;
+}
+
+/* 'reflect' (half-sample symmetric: d c b a | a b c d | d c b a), any distance */
+static int reflect_hs(int i, int n)
+{
+    if (n == 1) return 0;
+    int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+/* scipy ni_filters.c NI_Correlate1D, symmetric branch: centre tap first, then the pairs from the
+ * outermost inwards.  data: contiguous (n0,n1,n2) fp64, filtered along `axis`, out != data. */
+void fr3d_oracle_correlate1d_sym(const double *data, int n0, int n1, int n2, int axis, const double *w,
+                                 int radius, double *out)
+{
+    const int dims[3] = {n0, n1, n2};
+    const size_t strides[3] = {(size_t)n1 * n2, (size_t)n2, 1};
+    const int n = dims[axis];
+    const size_t st = strides[axis];
+    const double *fw = w + radius;
+    for (int a = 0; a < n0; a++)
+        for (int b = 0; b < n1; b++)
+            for (int c = 0; c < n2; c++) {
+                const int idx[3] = {a, b, c};
+                const int l = idx[axis];
+                const double *line = data + (size_t)a * strides[0] + (size_t)b * strides[1] + c - (size_t)l * st;
+                double tmp = line[(size_t)l * st] * fw[0];
+                for (int jj = -radius; jj < 0; jj++)
+                    tmp += (line[(size_t)reflect_hs(l + jj, n) * st] + line[(size_t)reflect_hs(l - jj, n) * st]) * fw[jj];
+                out[(size_t)a * strides[0] + (size_t)b * strides[1] + c] = tmp;
+            }
+}
+
+/* gaussian_filter(vol, sigma=(s0,s1,s2), mode="reflect", truncate) on (n0,n1,n2) fp64, in place;
+ * axes with sigma <= 1e-15 are skipped (scipy _filters.py gaussian_filter). */
+void fr3d_oracle_gaussian_filter3(double *vol, int n0, int n1, int n2, const double *sigma3, double truncate)
+{
+    size_t n = (size_t)n0 * n1 * n2;
+    double *tmp = (double *)xmalloc(sizeof(double) * n);
+    for (int axis = 0; axis < 3; axis++) {
+        if (!(sigma3[axis] > 1e-15)) continue;
+        int radius = fr3d_oracle_gaussian_kernel(sigma3[axis], truncate, NULL, 0);
+        double *w = (double *)xmalloc(sizeof(double) * (size_t)(2 * radius + 1));
+        fr3d_oracle_gaussian_kernel(sigma3[axis], truncate, w, 2 * radius + 1);
+        fr3d_oracle_correlate1d_sym(vol, n0, n1, n2, axis, w, radius, tmp);
+        memcpy(vol, tmp, sizeof(double) * n);
+        free(w);
+    }
+    free(tmp);
+}

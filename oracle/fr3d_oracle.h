@@ -75,6 +75,13 @@ int fr3d_oracle_get_displacement(const double *fixed, const double *moving, int 
                                  const double *a_data, const double *uvw, const double *weight,
                                  double *flow);
 
+/* scipy.ndimage gaussian kernel / symmetric correlate1d / gaussian_filter(mode="reflect") as
+ * util/image_processing_3D.py:95-162 uses them (fp64). */
+int fr3d_oracle_gaussian_kernel(double sigma, double truncate, double *w, int max_len);
+void fr3d_oracle_correlate1d_sym(const double *data, int n0, int n1, int n2, int axis, const double *w,
+                                 int radius, double *out);
+void fr3d_oracle_gaussian_filter3(double *vol, int n0, int n1, int n2, const double *sigma3, double truncate);
+
 #ifdef __cplusplus
 }
 #endif

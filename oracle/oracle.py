@@ -228,3 +228,61 @@ def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=2
     if rc != 0:
         raise ValueError("fr3d_oracle_get_displacement: bad arguments")
     return flow
+
+
+# ---- f-1 preprocessing (util/image_processing_3D.py) ---------------------------------------------
+
+def gaussian_filter3(vol, sigma_zyx, truncate=4.0):
+    """scipy.ndimage.gaussian_filter(vol, sigma=(sz,sy,sx), mode="reflect", truncate=truncate), fp64."""
+    a = np.array(vol, dtype=np.float64, order="C", copy=True)
+    s = (C.c_double * 3)(*[float(x) for x in sigma_zyx])
+    lib().fr3d_oracle_gaussian_filter3(_d(a), *map(C.c_int, a.shape), s, C.c_double(truncate))
+    return a
+
+
+def normalize(arr, ref=None, channel_normalization="together", eps=1e-8):
+    """util/image_processing_3D.py:12-92 (host arithmetic only; restated for the parity tests)."""
+    arr = np.asarray(arr)
+    if channel_normalization == "separate" and arr.ndim in (4, 5):
+        result = np.zeros_like(arr, dtype=np.float64)
+        for c in range(arr.shape[-1]):
+            src = ref[..., c] if (ref is not None and ref.ndim >= 4) else arr[..., c]
+            lo, hi = src.min(), src.max()
+            rng = hi - lo
+            result[..., c] = (arr[..., c] - lo) / rng if rng > 0 else arr[..., c] - lo
+        return result
+    src = ref if ref is not None else arr
+    lo, hi = src.min(), src.max()
+    if channel_normalization == "separate":
+        rng = hi - lo
+        return (arr - lo) / rng if rng > 0 else arr - lo
+    return (arr - lo) / (hi - lo + eps)
+
+
+def apply_gaussian_filter(arr, sigma, mode="reflect", truncate=4.0):
+    """util/image_processing_3D.py:95-162 for (Z,Y,X,C) and (T,Z,Y,X,C) with sigma (4,) or (C,4) =
+    [sx,sy,sz,st]; the temporal axis is filtered by the same symmetric correlate."""
+    assert mode == "reflect"
+    arr = np.asarray(arr)
+    sigma = np.asarray(sigma, dtype=np.float64)
+    out = np.zeros(arr.shape, np.float64)
+    nc = arr.shape[-1]
+    for c in range(nc):
+        s = sigma[min(c, len(sigma) - 1)] if sigma.ndim == 2 else sigma
+        if arr.ndim == 4:
+            out[..., c] = gaussian_filter3(arr[..., c], (s[2], s[1], s[0]), truncate)
+        else:
+            T = arr.shape[0]
+            vols = np.stack([arr[t, ..., c].astype(np.float64) for t in range(T)])
+            st = s[3] if len(s) == 4 else 0.0
+            if st > 1e-15:  # axis 0 of the 4-D filter comes first
+                radius = lib().fr3d_oracle_gaussian_kernel(C.c_double(st), C.c_double(truncate), None, 0)
+                w = np.empty(2 * radius + 1, np.float64)
+                lib().fr3d_oracle_gaussian_kernel(C.c_double(st), C.c_double(truncate), _d(w), w.size)
+                flat = np.ascontiguousarray(vols.reshape(T, 1, -1))
+                res = np.empty_like(flat)
+                lib().fr3d_oracle_correlate1d_sym(_d(flat), T, 1, flat.shape[2], 0, _d(w), radius, _d(res))
+                vols = res.reshape(vols.shape)
+            for t in range(T):
+                out[t, ..., c] = gaussian_filter3(vols[t], (s[2], s[1], s[0]), truncate)
+    return out

@@ -53,7 +53,7 @@ def test_struct_layouts_match_ctypes(lib, tmp_path):
 
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "flowreg3d_hip.h"\nint main(void){return FR3D_K_COUNT == 7 ? 0 : 1;}\n')
+    src.write_text('#include "flowreg3d_hip.h"\nint main(void){return FR3D_K_COUNT == 8 ? 0 : 1;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
                            "-o", str(tmp_path / "t")])
 

@@ -182,6 +182,28 @@ def main():
         save("schedule", rows=np.array(rows, dtype=np.float64),
              rounds=np.array([[x, round(x)] for x in (0.5, 1.5, 2.5, 40.96, 51.2, 20.48, 10.5, 11.5)], dtype=np.float64))
 
+    # ---- f-1: preprocessing (normalize + gaussian), reference util/image_processing_3D.py -------
+    if want("f1_preproc"):
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("im3d", os.path.join(REF_SRC, "flowreg3d", "util",
+                                                                           "image_processing_3D.py"))
+        im3d = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(im3d)
+        rng = np.random.Generator(np.random.PCG64(77))
+        batch = (rng.random((4, 7, 9, 11, 2)) * 900 + 50)
+        ref = (rng.random((7, 9, 11, 2)) * 1000)
+        sigma = np.array([[1.0, 1.2, 0.8, 0.6], [0.5, 2.0, 0.7, 0.1]])
+        out = dict(batch=batch, ref=ref, sigma=sigma, batch_u16=batch.astype(np.uint16))
+        for cn in ("together", "separate"):
+            n5 = im3d.normalize(batch, ref=ref, channel_normalization=cn)
+            out[f"norm5_{cn}"] = n5
+            out[f"filt5_{cn}"] = im3d.apply_gaussian_filter(n5, sigma, mode="reflect", truncate=4.0)
+            n4 = im3d.normalize(ref, ref=None, channel_normalization=cn)
+            out[f"filt4_{cn}"] = im3d.apply_gaussian_filter(n4, sigma, mode="reflect", truncate=4.0)
+        nu = im3d.normalize(batch.astype(np.uint16), ref=ref, channel_normalization="together")
+        out["filt5_u16"] = im3d.apply_gaussian_filter(nu, np.array([1.0, 1.0, 1.0, 0.1]), mode="reflect", truncate=4.0)
+        save("f1_preproc", **out)
+
     # ---- end to end --------------------------------------------------------------------------
     def e2e(name, shape, C, shift, kw, uvw_amp=0.0, weight=None):
         t0 = time.time()
