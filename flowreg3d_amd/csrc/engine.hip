@@ -217,7 +217,7 @@ struct Engine {
     {
         auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations);
         auto it = scheds.find(key);
-        if (it == scheds.end()) it = scheds.emplace(key, build_sor_schedule(sk, iterations)).first;
+        if (it == scheds.end()) it = scheds.emplace(key, build_sor_schedule(sk, iterations, sor_tile_rows(sk))).first;
         return it->second;
     }
     // profiling

@@ -30,16 +30,14 @@ namespace fr3d {
 
 #define SOR_OMEGA 1.95
 #define SOR_BX 64
-#ifndef SOR_BY
-#define SOR_BY 4
-#endif
+#define SOR_BY_MAX 4  // rows of a tile = blockDim.y (1, 2 or 4; chosen per level, see sor_tile_rows)
 
 template <typename R> __device__ __forceinline__ R fma_(R a, R b, R c);
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
 
 template <typename R, typename S, int C>
-__global__ void __launch_bounds__(SOR_BX * SOR_BY)
+__global__ void __launch_bounds__(SOR_BX * SOR_BY_MAX)
 k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent)
 {
     const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X, Yp = a.sk.Yp;
@@ -58,7 +56,7 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
     const int local = b - en.pre;
     const int t = t_lo + lo;
     const int s = tau - 2 * t;
-    const int k = (en.kb0 + local / en.njb) * SOR_BY + threadIdx.y;
+    const int k = (en.kb0 + local / en.njb) * (int)blockDim.y + threadIdx.y;
     if (k >= Z) return;
     const int r = s - k;                       // i + j of this row
     const int jm0 = sk_jm(X, r);               // first valid j of the row (left-aligned storage)
@@ -184,9 +182,9 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
 
 template <typename R, typename S>
 static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo, int nt, int ntiles,
-                        const SorEntry *ent)
+                        const SorEntry *ent, int by)
 {
-    dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, SOR_BY);
+    dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, by);
     switch (a.C) {
         case 1: hipLaunchKernelGGL((k_sor_step<R, S, 1>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
         case 2: hipLaunchKernelGGL((k_sor_step<R, S, 2>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
@@ -196,9 +194,20 @@ static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo,
     }
 }
 
-SorSched build_sor_schedule(const Skew &sk, int T)
+int sor_tile_rows(const Skew &sk)
+{
+    static const char *env = getenv("FR3D_SOR_BY");
+    if (env) {
+        const int v = atoi(env);
+        if (v == 1 || v == 2 || v == 4) return v;
+    }
+    return (sk.X >= 320 && sk.Y >= 320) ? 2 : 4;
+}
+
+SorSched build_sor_schedule(const Skew &sk, int T, int by)
 {
     SorSched sc;
+    sc.by = by;
     const int S = sk.S, Z = sk.Z, Y = sk.Y, X = sk.X;
     std::vector<SorEntry> ent;
     if (T <= 0) return sc;
@@ -233,7 +242,7 @@ SorSched build_sor_schedule(const Skew &sk, int T)
                     if (len > maxlen) maxlen = len;
                 }
                 if (maxlen > 0) {
-                    const int kb0 = klo / SOR_BY, kb1 = khi / SOR_BY;
+                    const int kb0 = klo / by, kb1 = khi / by;
                     e.kb0 = (short)kb0;
                     e.njb = (short)cdiv(maxlen, SOR_BX);
                     pre += (kb1 - kb0 + 1) * e.njb;
@@ -264,8 +273,8 @@ long long launch_sor(hipStream_t st, const SorArgsT<S> &a_in, bool fp64, const S
     for (size_t l = 0; l < sc.tau.size(); l++) {
         if (sc.ntiles[l] <= 0) continue;
         const SorEntry *ent = sc.entries + sc.first[l];
-        if (fp64 || sizeof(S) == 8) launch_step<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent);
-        else launch_step<float, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent);
+        if (fp64 || sizeof(S) == 8) launch_step<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent, sc.by);
+        else launch_step<float, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent, sc.by);
         launches++;
     }
     return launches;
