@@ -74,6 +74,8 @@ SIGNATURES = {
                                   _vp, C.c_int]),
     "fr3d_preprocess_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_double, _vp, C.c_int]),
+    "fr3d_flow_stats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
+    "fr3d_flow_stats_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "fr3d_resize3d": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_motion_tensor": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "fr3d_level_solve": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,

@@ -1001,6 +1001,49 @@ int fr3d_preprocess(const void *frames, int dtype, int T, int Z, int Y, int X, i
     FR3D_CATCH
 }
 
+static void flow_stats_dev(const float *flows, int T, int Z, int Y, int X, double *out)
+{
+    ensure_init();
+    FR3D_CHECK(flows && out && T >= 0 && Z >= 1 && Y >= 1 && X >= 1, "bad flow_stats arguments");
+    Engine &e = g_eng;
+    const long long n = (long long)Z * Y * X;
+    const int nb = (int)std::min<long long>(1024, (n + 255) / 256);
+    double *dpart = e.f64("stats_part", (size_t)nb * 6);
+    std::vector<double> hpart((size_t)nb * 6);
+    for (int t = 0; t < T; t++) {
+        launch_flow_stats(e.st, flows + (size_t)t * n * 3, Z, Y, X, nb, dpart);
+        FR3D_HIP(hipMemcpyAsync(hpart.data(), dpart, hpart.size() * sizeof(double), hipMemcpyDeviceToHost, e.st));
+        FR3D_HIP(hipStreamSynchronize(e.st));
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < nb; b++)
+            for (int q = 0; q < 6; q++) {
+                if (q == 1) acc[q] = std::max(acc[q], hpart[(size_t)b * 6 + q]);
+                else acc[q] += hpart[(size_t)b * 6 + q];
+            }
+        double *o = out + (size_t)t * 6;
+        o[0] = acc[0] / (double)n; o[1] = acc[1]; o[2] = acc[2] / (double)n;
+        o[3] = acc[3] / (double)n; o[4] = acc[4] / (double)n; o[5] = acc[5] / (double)n;
+    }
+}
+
+int fr3d_flow_stats_dev(const float *flows, int T, int Z, int Y, int X, double *out)
+{
+    FR3D_TRY
+    flow_stats_dev(flows, T, Z, Y, X, out);
+    FR3D_CATCH
+}
+
+int fr3d_flow_stats(const float *flows, int T, int Z, int Y, int X, double *out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(flows && out && T >= 0 && Z >= 1 && Y >= 1 && X >= 1, "bad flow_stats arguments");
+    Staged s;
+    const float *d = (const float *)s.up(flows, (size_t)T * Z * Y * X * 3 * 4);
+    flow_stats_dev(d, T, Z, Y, X, out);
+    FR3D_CATCH
+}
+
 // ---- kernel-level entry points ------------------------------------------------------------------
 
 int fr3d_resize3d(const float *src, int D, int H, int W, int od, int oh, int ow, float *dst)

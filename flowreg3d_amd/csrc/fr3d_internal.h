@@ -174,6 +174,9 @@ void launch_gauss_pass(hipStream_t st, const TIN *in, int cs, int co, double nmi
 template <typename TOUT>
 void launch_store_channel(hipStream_t st, const double *in, long long n, int C, int c, TOUT *out);
 
+// f-2 statistics (k_misc.hip): partial = nblocks x 6 doubles (sum|w|, max|w|, sum div, sum u, sum v, sum w)
+void launch_flow_stats(hipStream_t st, const float *flow, int Z, int Y, int X, int nblocks, double *partial);
+
 // K9 pointwise helpers
 void launch_axpy(hipStream_t st, float *y, const float *x, long long n);  // y += x
 void launch_fill(hipStream_t st, float *y, float v, long long n);

@@ -53,3 +53,59 @@ void launch_unpack(hipStream_t st, const float *inter, int C, long long n, float
 }
 
 }  // namespace fr3d
+
+// ---- f-2: per-volume flow statistics (motion_correction/compensate_recording_3D.py:488-508) ----
+// |w| mean and max, mean divergence (np.gradient: central differences, one-sided at the ends,
+// unit spacing) and mean u,v,w of a (Z,Y,X,3) fp32 flow.  Per-voxel values are formed in fp32
+// exactly like NumPy does on the float32 flow; sums are accumulated in fp64 per block and finished
+// on the host (deterministic, no atomics).
+namespace fr3d {
+
+__global__ void __launch_bounds__(256)
+k_flow_stats(const float *__restrict__ flow, int Z, int Y, int X, double *__restrict__ partial)
+{
+    const long long n = (long long)Z * Y * X;
+    double s_mag = 0, s_div = 0, s_u = 0, s_v = 0, s_w = 0;
+    float m_mag = 0.0f;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % X);
+        const long long r = e / X;
+        const int y = (int)(r % Y), z = (int)(r / Y);
+        const float u = flow[e * 3 + 0], v = flow[e * 3 + 1], w = flow[e * 3 + 2];
+        const float mag = sqrtf(u * u + v * v + w * w);
+        s_mag += (double)mag;
+        m_mag = fmaxf(m_mag, mag);
+        s_u += (double)u; s_v += (double)v; s_w += (double)w;
+        auto grad = [&](int pos, int len, long long stride, int comp) -> float {
+            if (len == 1) return 0.0f;  // np.gradient needs >= 2 samples; the pipeline never has 1
+            const float *p = flow + e * 3 + comp;
+            if (pos == 0) return (p[stride * 3] - p[0]) / 1.0f;
+            if (pos == len - 1) return (p[0] - p[-stride * 3]) / 1.0f;
+            return (p[stride * 3] - p[-stride * 3]) / 2.0f;
+        };
+        const float dux = grad(x, X, 1, 0), dvy = grad(y, Y, X, 1), dwz = grad(z, Z, (long long)Y * X, 2);
+        s_div += (double)((dux + dvy) + dwz);
+    }
+    __shared__ double sh[6][256];
+    sh[0][threadIdx.x] = s_mag; sh[1][threadIdx.x] = (double)m_mag; sh[2][threadIdx.x] = s_div;
+    sh[3][threadIdx.x] = s_u; sh[4][threadIdx.x] = s_v; sh[5][threadIdx.x] = s_w;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                if (q == 1) sh[q][threadIdx.x] = fmax(sh[q][threadIdx.x], sh[q][threadIdx.x + off]);
+                else sh[q][threadIdx.x] += sh[q][threadIdx.x + off];
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) partial[(size_t)blockIdx.x * 6 + threadIdx.x] = sh[threadIdx.x][0];
+}
+
+void launch_flow_stats(hipStream_t st, const float *flow, int Z, int Y, int X, int nblocks, double *partial)
+{
+    hipLaunchKernelGGL(k_flow_stats, dim3(nblocks), dim3(256), 0, st, flow, Z, Y, X, partial);
+}
+
+}  // namespace fr3d

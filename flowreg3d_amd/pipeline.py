@@ -1,0 +1,236 @@
+"""Batch driver around the executor: what
+``BatchMotionCorrector.run`` (motion_correction/compensate_recording_3D.py:431-555) and
+``compensate_arr_3D`` (motion_correction/compensate_arr_3D.py:13-143) do for in-memory arrays,
+with the per-voxel work on the device:
+
+  reference: weights (:212-224), reference_proc = preprocess(reference_raw) (:227)
+  per batch of ``buffer_size`` volumes: preprocess against the reference's range (:461-463),
+  first batch: w_init = mean flow of the first min(22,T) volumes solved from zero (:342-393),
+  executor.process_batch (:476-478), w_init <- mean of the last <= 20 flows (:481-485),
+  statistics mean/max |w|, mean divergence, mean translation (:488-508).
+
+The file formats, readers/writers and the pydantic ``OFOptions`` model are out of scope; ``Options``
+below carries the fields of OFOptions this driver reads (OF_options_3D.py:155-231) with the same
+defaults, and any object with those attributes (an actual OFOptions included) is accepted.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any, Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .executor import HipExecutor3D
+from .preprocess import preprocess_frames
+
+_OUT_DTYPES = {"single": np.float32, "double": np.float64, "uint8": np.uint8, "uint16": np.uint16,
+               "int16": np.int16, "int32": np.int32}
+
+
+@dataclass
+class Options:
+    """Subset of OFOptions (motion_correction/OF_options_3D.py:155-231), same defaults."""
+    alpha: Any = (0.25, 0.25, 0.25)
+    weight: Any = field(default_factory=lambda: [0.5, 0.5])
+    levels: int = 100
+    min_level: int = 5
+    quality_setting: str = "quality"
+    eta: float = 0.8
+    update_lag: int = 5
+    iterations: int = 100
+    a_smooth: float = 1.0
+    a_data: float = 0.45
+    sigma: Any = field(default_factory=lambda: [[1.0, 1.0, 1.0, 0.1], [1.0, 1.0, 1.0, 0.1]])
+    buffer_size: int = 10
+    output_typename: Optional[str] = "double"
+    channel_normalization: str = "together"
+    interpolation_method: str = "cubic"
+    update_initialization_w: bool = True
+    solver_fp64: int = 0  # extension: 2 selects fp64 solver storage
+
+    @property
+    def effective_min_level(self) -> int:
+        """OF_options_3D.py:329-341"""
+        if self.min_level >= 0:
+            return self.min_level
+        return {"quality": 0, "balanced": 4, "fast": 6}.get(str(self.quality_setting), 0)
+
+
+def _alpha3(alpha):
+    """OF_options_3D.py:239-264: scalar / 2-tuple / 3-tuple -> 3-tuple."""
+    a = np.asarray(alpha, dtype=np.float64).reshape(-1)
+    if a.size == 1:
+        return (float(a[0]),) * 3
+    if a.size == 2:
+        return (float(a[0]), float(a[1]), float(a[1]))
+    if a.size == 3:
+        return tuple(float(x) for x in a)
+    raise ValueError("alpha must have 1, 2 or 3 entries")
+
+
+def _weight_at(weight, i, n_channels):
+    """OFOptions.get_weight_at (OF_options_3D.py:371-399)."""
+    w = np.asarray(weight, dtype=float)
+    if w.ndim <= 1:
+        if w.size == 1:
+            return float(w.reshape(-1)[0])
+        if w.size > n_channels:
+            w = w[:n_channels]
+            w = w / w.sum()
+        if i >= w.size:
+            return 1.0 / n_channels
+        return float(w[i])
+    if i >= w.shape[0]:
+        return np.ones(w.shape[1:]) / n_channels
+    return w[i]
+
+
+def _opt(options, name, default):
+    v = getattr(options, name, default)
+    return getattr(v, "value", v)  # enums of the real OFOptions
+
+
+@dataclass
+class BatchStats:
+    mean_disp: List[float] = field(default_factory=list)
+    max_disp: List[float] = field(default_factory=list)
+    mean_div: List[float] = field(default_factory=list)
+    mean_translation: List[float] = field(default_factory=list)
+
+
+def flow_statistics(w: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+    """Per-volume (mean |w|, max |w|, mean divergence, |mean translation|) on the device
+    (compensate_recording_3D.py:488-508)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    T, Z, Y, X, _ = w.shape
+    out = np.zeros((T, 6), np.float64)
+    lib = _lib.init()
+    _lib.check(lib.fr3d_flow_stats(_lib.ptr(w), T, Z, Y, X, out.ctypes.data_as(C.POINTER(C.c_double))))
+    trans = np.sqrt(out[:, 3] ** 2 + out[:, 4] ** 2 + out[:, 5] ** 2)
+    return out[:, 0], out[:, 1], out[:, 2], trans
+
+
+class BatchMotionCorrectorHip:
+    """In-memory counterpart of BatchMotionCorrector for (T,Z,Y,X,C) arrays."""
+
+    def __init__(self, options: Any = None, executor=None):
+        self.options = options if options is not None else Options()
+        self.executor = executor if executor is not None else HipExecutor3D()
+        self.stats = BatchStats()
+        self.w_init: Optional[np.ndarray] = None
+        self._callbacks: List[Callable[[int, int], None]] = []
+
+    def register_progress_callback(self, cb: Callable[[int, int], None]):
+        self._callbacks.append(cb)
+
+    # -- pieces of BatchMotionCorrector ------------------------------------------------------
+    def _flow_params(self) -> dict:
+        o = self.options
+        return {"alpha": _alpha3(_opt(o, "alpha", (0.25,) * 3)), "weight": self.weight,
+                "levels": int(_opt(o, "levels", 100)),
+                "min_level": int(getattr(o, "effective_min_level", getattr(o, "min_level", 0))),
+                "eta": float(_opt(o, "eta", 0.8)), "update_lag": int(_opt(o, "update_lag", 5)),
+                "iterations": int(_opt(o, "iterations", 100)), "a_smooth": float(_opt(o, "a_smooth", 1.0)),
+                "a_data": _opt(o, "a_data", 0.45), "solver_fp64": int(_opt(o, "solver_fp64", 0))}
+
+    def _preprocess(self, frames, normalization_ref=None):
+        return preprocess_frames(frames, normalization_ref=normalization_ref, sigma=np.asarray(_opt(self.options, "sigma", None)),
+                                 channel_normalization=str(_opt(self.options, "channel_normalization", "together")))
+
+    def _setup_reference(self, reference: np.ndarray):
+        self.reference_raw = np.asarray(reference).astype(np.float64)
+        Z, Y, X = self.reference_raw.shape[:3]
+        nc = self.reference_raw.shape[3]
+        self.weight = np.ones((Z, Y, X, nc), np.float64)
+        for c in range(nc):
+            self.weight[..., c] = _weight_at(_opt(self.options, "weight", [1.0] * nc), c, nc)
+        self.reference_proc = self._preprocess(self.reference_raw)
+
+    def _process(self, batch, batch_proc, w_init, notify):
+        cb = None
+        if notify and self._callbacks:
+            def cb(n):
+                self._done += int(n)
+                for f in self._callbacks:
+                    f(self._done, self._total)
+        return self.executor.process_batch(batch, batch_proc, self.reference_raw, self.reference_proc, w_init,
+                                           None, None,
+                                           interpolation_method=str(_opt(self.options, "interpolation_method", "cubic")),
+                                           progress_callback=cb, flow_params=self._flow_params())
+
+    def run(self, video: np.ndarray, reference: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        video = np.asarray(video)
+        T = video.shape[0]
+        self._total, self._done = T, 0
+        self._setup_reference(reference)
+        Z, Y, X, nc = self.reference_raw.shape
+        registered = np.empty_like(video)
+        flows = np.empty((T, Z, Y, X, 3), np.float32)
+        bs = max(1, int(_opt(self.options, "buffer_size", 10)))
+        self.executor.setup()
+        try:
+            for bi, t0 in enumerate(range(0, T, bs)):
+                batch = video[t0:t0 + bs]
+                batch_proc = self._preprocess(batch, normalization_ref=self.reference_raw)
+                if bi == 0:
+                    # w_init from the first min(22, T) volumes solved from zero (:342-393)
+                    n_init = min(22, batch.shape[0])
+                    _, w0 = self._process(batch[:n_init], batch_proc[:n_init], np.zeros((Z, Y, X, 3), np.float32), False)
+                    self.w_init = np.mean(w0, axis=0)
+                use_init = bool(_opt(self.options, "update_initialization_w", True))
+                cur = self.w_init if use_init else np.zeros_like(self.w_init)
+                reg, w = self._process(batch, batch_proc, cur, True)
+                if use_init:
+                    self.w_init = np.mean(w[-20:], axis=0) if w.shape[0] > 20 else np.mean(w, axis=0)
+                md, mx, dv, tr = flow_statistics(w)
+                self.stats.mean_disp.extend(md.tolist())
+                self.stats.max_disp.extend(mx.tolist())
+                self.stats.mean_div.extend(dv.tolist())
+                self.stats.mean_translation.extend(tr.tolist())
+                registered[t0:t0 + bs] = reg
+                flows[t0:t0 + bs] = w
+        finally:
+            self.executor.cleanup()
+        return registered, flows
+
+
+def compensate_arr_3D(c1: np.ndarray, c_ref: np.ndarray, options: Any = None,
+                      progress_callback: Optional[Callable[[int, int], None]] = None,
+                      return_stats: bool = False):
+    """motion_correction/compensate_arr_3D.py:13-143 on the MI355X engine.
+
+    c1: (T,Z,Y,X,C), (T,Z,Y,X) with a 3-D reference, or a single (Z,Y,X) volume; c_ref: (Z,Y,X[,C]).
+    Returns (c_reg with the input's shape, w (T,Z,Y,X,3) float32 [squeezed like the reference])."""
+    c1 = np.asarray(c1)
+    c_ref = np.asarray(c_ref)
+    if c1.size == 0:
+        raise ValueError("Input array cannot be empty")
+    squeezed = False
+    original_shape = c1.shape
+    if c1.ndim == 4 and c_ref.ndim == 3:
+        c1 = c1[..., np.newaxis]
+        c_ref = c_ref[..., np.newaxis]
+        squeezed = True
+    elif c1.ndim == 3:
+        c1 = c1[np.newaxis, :, :, :, np.newaxis]
+        if c_ref.ndim == 3:
+            c_ref = c_ref[..., np.newaxis]
+        squeezed = True
+    if c1.ndim != 5 or c_ref.ndim != 4 or c1.shape[1:] != c_ref.shape:
+        raise ValueError(f"incompatible shapes {original_shape} / {c_ref.shape}")
+    corrector = BatchMotionCorrectorHip(options)
+    if progress_callback is not None:
+        corrector.register_progress_callback(progress_callback)
+    c_reg, w = corrector.run(c1, c_ref)
+    typename = _opt(corrector.options, "output_typename", None)
+    if typename in _OUT_DTYPES:
+        c_reg = c_reg.astype(_OUT_DTYPES[typename])
+    if squeezed:
+        if len(original_shape) == 3:
+            c_reg = np.squeeze(c_reg)
+            w = np.squeeze(w, axis=0)
+        else:
+            c_reg = c_reg[..., 0]
+    return (c_reg, w, corrector.stats) if return_stats else (c_reg, w)

@@ -120,6 +120,13 @@ int fr3d_preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int 
                         const double *norm_min, const double *norm_den, const double *sigma,
                         double truncate, void *out, int out_dtype);
 
+/* Per-volume displacement statistics of the batch driver (SURVEY section 8 f-2;
+ * motion_correction/compensate_recording_3D.py:488-508).  flows: (T,Z,Y,X,3) fp32;
+ * out (host): T x 6 doubles = mean|w|, max|w|, mean divergence (np.gradient, unit spacing),
+ * mean u, mean v, mean w. */
+int fr3d_flow_stats(const float *flows, int T, int Z, int Y, int X, double *out);
+int fr3d_flow_stats_dev(const float *flows, int T, int Z, int Y, int X, double *out);
+
 /* ---- kernel-level entry points (stage parity tests; host pointers) ---------------------- */
 
 /* imresize_fused_gauss_cubic3D (util/resize_util_3D.py:114-156), one fp32 channel. */

@@ -1,0 +1,109 @@
+"""-m gpu: the batch driver -- preprocessing, w_init bootstrap and propagation,
+executor, statistics -- against the same driver restated on the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _video(T=6, shape=(10, 16, 18), C=1):
+    from flowreg3d_amd.synthetic import make_pair
+    fixed, _, _ = make_pair(shape, seed=31, channels=C)
+    vols = [make_pair(shape, seed=31, channels=C, scale=0.15 * (t + 1))[1] for t in range(T)]
+    v = np.stack(vols).astype(np.float32)
+    if C == 1:
+        v, fixed = v[..., None], fixed[..., None]
+    return (v * 1000 + 100).astype(np.float32), (fixed * 1000 + 100).astype(np.float32)
+
+
+def _oracle_driver(oracle, video, reference, opt):
+    """BatchMotionCorrector.run (compensate_recording_3D.py:431-555) on the oracle."""
+    from flowreg3d_amd.pipeline import _alpha3, _weight_at
+    ref_raw = reference.astype(np.float64)
+    Z, Y, X, nc = ref_raw.shape
+    weight = np.ones((Z, Y, X, nc))
+    for c in range(nc):
+        weight[..., c] = _weight_at(opt.weight, c, nc)
+    pre = lambda fr, ref=None: oracle.apply_gaussian_filter(
+        oracle.normalize(fr, ref=ref, channel_normalization=opt.channel_normalization), np.asarray(opt.sigma))
+    ref_proc = pre(ref_raw)
+    fp = dict(alpha=_alpha3(opt.alpha), weight=weight, levels=opt.levels, min_level=opt.effective_min_level,
+              eta=opt.eta, update_lag=opt.update_lag, iterations=opt.iterations, a_smooth=opt.a_smooth, a_data=opt.a_data)
+
+    def process(batch, batch_proc, w_init):
+        reg = np.empty_like(batch)
+        fl = np.empty(batch.shape[:4] + (3,), np.float32)
+        for t in range(batch.shape[0]):
+            f = oracle.get_displacement(ref_proc, batch_proc[t], uvw=w_init.copy(), **fp).astype(np.float32)
+            reg[t] = oracle.imregister_wrapper(batch[t], f[..., 0], f[..., 1], f[..., 2], ref_raw,
+                                               opt.interpolation_method).reshape(reg[t].shape)
+            fl[t] = f
+        return reg, fl
+
+    regs, flows, stats = [], [], dict(mean_disp=[], max_disp=[], mean_div=[], mean_translation=[])
+    w_init = None
+    for bi, t0 in enumerate(range(0, video.shape[0], opt.buffer_size)):
+        batch = video[t0:t0 + opt.buffer_size]
+        bp = pre(batch, ref_raw)
+        if bi == 0:
+            n_init = min(22, batch.shape[0])
+            _, w0 = process(batch[:n_init], bp[:n_init], np.zeros((Z, Y, X, 3)))
+            w_init = np.mean(w0, axis=0)
+        reg, w = process(batch, bp, w_init)
+        w_init = np.mean(w[-20:], axis=0) if w.shape[0] > 20 else np.mean(w, axis=0)
+        mag = np.sqrt(w[..., 0] ** 2 + w[..., 1] ** 2 + w[..., 2] ** 2)
+        stats["mean_disp"] += np.mean(mag, axis=(1, 2, 3)).tolist()
+        stats["max_disp"] += np.max(mag, axis=(1, 2, 3)).tolist()
+        for t in range(w.shape[0]):
+            div = np.gradient(w[t, ..., 0], axis=2) + np.gradient(w[t, ..., 1], axis=1) + np.gradient(w[t, ..., 2], axis=0)
+            stats["mean_div"].append(float(np.mean(div)))
+            stats["mean_translation"].append(float(np.sqrt(np.mean(w[t, ..., 0]) ** 2 + np.mean(w[t, ..., 1]) ** 2
+                                                           + np.mean(w[t, ..., 2]) ** 2)))
+        regs.append(reg)
+        flows.append(w)
+    return np.concatenate(regs), np.concatenate(flows), stats
+
+
+def test_compensate_arr_matches_oracle_driver(hip, oracle):
+    from flowreg3d_amd.pipeline import Options, compensate_arr_3D
+    video, ref = _video()
+    opt = Options(min_level=0, levels=3, iterations=12, update_lag=4, buffer_size=4, output_typename=None,
+                  sigma=[[1.0, 0.8, 0.6, 0.5]], solver_fp64=2)
+    seen = []
+    reg, w, stats = compensate_arr_3D(video, ref, opt, progress_callback=lambda a, b: seen.append((a, b)),
+                                      return_stats=True)
+    assert reg.shape == video.shape and reg.dtype == video.dtype and w.shape == video.shape[:4] + (3,)
+    assert seen[-1] == (video.shape[0], video.shape[0]) and [a for a, _ in seen] == sorted(a for a, _ in seen)
+    reg_o, w_o, st_o = _oracle_driver(oracle, video, ref, opt)
+    epe = np.linalg.norm(w.astype(np.float64) - w_o, axis=-1)
+    assert epe.mean() < 1e-4, (epe.mean(), epe.max())
+    assert np.abs(reg - reg_o).max() < 0.5  # intensities ~100..1100: 5e-4 relative
+    for k in ("mean_disp", "max_disp", "mean_translation"):
+        assert np.allclose(getattr(stats, k), st_o[k], rtol=1e-4, atol=1e-5), k
+    assert np.allclose(stats.mean_div, st_o["mean_div"], rtol=1e-3, atol=2e-6)
+
+
+def test_compensate_arr_shapes_and_dtypes(hip):
+    from flowreg3d_amd.pipeline import Options, compensate_arr_3D
+    video, ref = _video(T=3)
+    opt = Options(min_level=0, levels=2, iterations=5, buffer_size=2)
+    reg, w = compensate_arr_3D(video[..., 0], ref[..., 0], opt)          # (T,Z,Y,X) + 3-D reference
+    assert reg.shape == video.shape[:4] and reg.dtype == np.float64 and w.shape == video.shape[:4] + (3,)
+    reg1, w1 = compensate_arr_3D(video[0, ..., 0], ref[..., 0], Options(min_level=0, levels=2, iterations=5,
+                                                                        output_typename="uint16"))
+    assert reg1.shape == video.shape[1:4] and reg1.dtype == np.uint16 and w1.shape == video.shape[1:4] + (3,)
+    with pytest.raises(ValueError):
+        compensate_arr_3D(np.zeros((0, 4, 4, 4, 1)), ref, opt)
+
+
+def test_flow_statistics_vs_numpy(hip):
+    from flowreg3d_amd.pipeline import flow_statistics
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((2, 7, 9, 11, 3)).astype(np.float32)
+    md, mx, dv, tr = flow_statistics(w)
+    mag = np.sqrt(w[..., 0] ** 2 + w[..., 1] ** 2 + w[..., 2] ** 2)
+    assert np.allclose(md, mag.mean(axis=(1, 2, 3)), rtol=1e-6)
+    assert np.array_equal(mx.astype(np.float32), mag.max(axis=(1, 2, 3)))
+    for t in range(2):
+        div = np.gradient(w[t, ..., 0], axis=2) + np.gradient(w[t, ..., 1], axis=1) + np.gradient(w[t, ..., 2], axis=0)
+        assert abs(dv[t] - float(div.mean())) < 1e-6

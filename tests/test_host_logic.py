@@ -121,3 +121,21 @@ def test_shard_indices():
     assert shard_indices(2, 3, 4) == []
     with pytest.raises(ValueError):
         shard_indices(4, 4, 4)
+
+
+def test_pipeline_option_helpers_follow_ofoptions():
+    """OF_options_3D.py:239-264 (alpha), :329-341 (effective_min_level), :371-399 (get_weight_at)."""
+    from flowreg3d_amd.pipeline import Options, _alpha3, _weight_at
+    assert _alpha3(2.0) == (2.0, 2.0, 2.0) and _alpha3((1.0, 2.0)) == (1.0, 2.0, 2.0) and _alpha3((1, 2, 3)) == (1.0, 2.0, 3.0)
+    with pytest.raises(ValueError):
+        _alpha3((1, 2, 3, 4))
+    o = Options()
+    assert o.effective_min_level == 5 and o.iterations == 100 and o.update_lag == 5 and o.a_smooth == 1.0
+    assert Options(min_level=-1, quality_setting="balanced").effective_min_level == 4
+    assert Options(min_level=-1, quality_setting="fast").effective_min_level == 6
+    assert Options(min_level=-1).effective_min_level == 0
+    assert _weight_at([0.5, 0.5], 0, 1) == 1.0            # truncated and renormalised
+    assert _weight_at([0.7, 0.3], 1, 2) == 0.3
+    assert _weight_at([0.6], 0, 2) == 0.6 and _weight_at([0.6, 0.4], 2, 3) == pytest.approx(1 / 3)
+    w3 = np.arange(2 * 2 * 2 * 2, dtype=float).reshape(2, 2, 2, 2)
+    assert np.array_equal(_weight_at(w3, 1, 2), w3[1])
