@@ -79,7 +79,7 @@ SIGNATURES = {
     "fr3d_resize3d": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_motion_tensor": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "fr3d_level_solve": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,
-                                   C.c_double, C.c_double, C.c_double, C.c_int, _vp]),
+                                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _vp]),
     "fr3d_median5": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _ip, C.c_int, _ip]),
     "fr3d_dev_malloc": (C.c_void_p, [C.c_size_t]),

@@ -94,9 +94,6 @@ def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=2
         moving = moving[..., None]
     if fixed.ndim != 4 or moving.shape != fixed.shape:
         raise ValueError("fixed and moving must have the same (Z,Y,X[,C]) shape")
-    if float(a_smooth) != 1.0:
-        raise NotImplementedError("a_smooth != 1.0 is not implemented on the device yet "
-                                  "(OFOptions default is 1.0; see DESIGN.md, out of scope)")
     p, m, n, nc = fixed.shape
     wt = expand_weight(weight, p, m, n, nc)
     params = _lib.make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth, a_data, nc,
@@ -233,8 +230,6 @@ def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v,
     interior (the reference leaves the Neumann copy of the previous iterate there; it is never read
     downstream, core/optical_flow_3d.py:517-535).  The tensor must be the rank-3 gradient-constancy
     tensor get_motion_tensor_gc produces (see tensor_factors)."""
-    if float(a_smooth) != 1.0:
-        raise NotImplementedError("a_smooth != 1.0 is not implemented on the device yet")
     Js = [np.asarray(j) for j in (J11, J22, J33, J44, J12, J13, J23, J14, J24, J34)]
     if Js[0].ndim == 3:
         Js = [j[..., None] for j in Js]
@@ -259,8 +254,8 @@ def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v,
     ad = (C.c_double * nc)(*[float(x) for x in ad_np])
     lib = _lib.init()
     _lib.check(lib.fr3d_level_solve(_lib.ptr(Ad), _lib.ptr(wd), _lib.ptr(uvw), P - 2, M - 2, N - 2,
-                                    nc, al, int(iterations), int(update_lag), ad, float(hx), float(hy),
-                                    float(hz), 1 if solver_fp64 else 0, _lib.ptr(out)))
+                                    nc, al, int(iterations), int(update_lag), ad, float(a_smooth), float(hx),
+                                    float(hy), float(hz), 1 if solver_fp64 else 0, _lib.ptr(out)))
     return tuple(np.pad(out[d].astype(np.float64), 1, mode="edge") for d in range(3))
 
 

@@ -392,7 +392,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                                     int reserve_nb)
 {
     const std::string sn = sizeof(S) == 8 ? "64" : "";  // separate workspaces per storage type
-    FR3D_CHECK(p.a_smooth == 1.0, "a_smooth != 1 is not implemented on the device (SURVEY 8f-3)");
+    FR3D_CHECK(p.a_smooth >= 0.0, "a_smooth must be >= 0");
     FR3D_CHECK(nb >= 1 && nb <= 64, "internal: bad batch size");
     const size_t nfull = (size_t)Z * Y * X;
     std::vector<float *> uvw(3 * nb, nullptr), uvw_prev(3 * nb, nullptr);
@@ -493,10 +493,47 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         }
         a.iterations = p.iterations;
         a.update_lag = p.update_lag;
-        {
+        if (p.a_smooth == 1.0) {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
             long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
             sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
+        } else {
+            // a_smooth != 1 (k_sor_smooth.hip): psi_smooth every iteration, triple-buffered increments,
+            // one volume at a time; the result is copied into the batch slab the common tail reads
+            Span sp(e, FR3D_K_SOR, 0, 0, 0);
+            S *smU = (S *)e.bufs["sm_U" + sn].ensure(ns * 3 * sizeof(S));
+            S *smD = (S *)e.bufs["sm_D" + sn].ensure(ns * 9 * sizeof(S));
+            S *smP = (S *)e.bufs["sm_P" + sn].ensure(ns * sizeof(S));
+            for (int b = 0; b < nb; b++) {
+                SmoothArgs<S> sa;
+                std::memset(&sa, 0, sizeof(sa));
+                sa.view.Z = lz; sa.view.Y = ly; sa.view.X = lx; sa.view.Yp = sk.Yp; sa.view.plane = sk.plane;
+                sa.view.hx = hx; sa.view.hy = hy; sa.view.hz = hz; sa.view.a_smooth = p.a_smooth;
+                for (int d = 0; d < 3; d++) {
+                    launch_skew_copy_n<float, S>(e.st, uvw[3 * b + d], 0, smU + (size_t)d * ns, 0, 1, sk);
+                    sa.view.U[d] = smU + (size_t)d * ns;
+                    for (int q = 0; q < 3; q++) sa.D[q][d] = smD + ((size_t)q * 3 + d) * ns;
+                }
+                FR3D_HIP(hipMemsetAsync(smD, 0, ns * 9 * sizeof(S), e.st));
+                sa.Ps = smP;
+                for (int q = 0; q < 9; q++) sa.M[q] = a.M[q] + (size_t)b * a.vsM;
+                for (int c = 0; c < C; c++) {
+                    for (int q = 0; q < 12; q++)
+                        sa.A[q * FR3D_MAX_CHANNELS + c] = a.A[q * FR3D_MAX_CHANNELS + c] + (size_t)b * a.vsA;
+                    sa.weight[c] = a.weight[c];
+                    sa.a_data[c] = p.a_data[c];
+                }
+                sa.ax = a.ax; sa.ay = a.ay; sa.az = a.az;
+                sa.C = C;
+                sa.iterations = p.iterations;
+                sa.update_lag = p.update_lag;
+                sa.S_planes = sk.S;
+                long long n = launch_sor_smooth<S>(e.st, sa);
+                if (p.iterations > 0)
+                    FR3D_HIP(hipMemcpyAsync(dbuf + (size_t)b * a.vsD, sa.D[(p.iterations - 1) % 3][0], ns * 3 * sizeof(S),
+                                            hipMemcpyDeviceToDevice, e.st));
+                sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations, n, (long long)nl * p.iterations);
+            }
         }
         // increments back to the natural layout, 5^3 median (:517-526), accumulate (:527-529)
         const bool med = std::min(lz, std::min(ly, lx)) > 5;
@@ -1082,8 +1119,8 @@ int fr3d_motion_tensor(const float *f1, const float *f2, int Z, int Y, int X, do
 }
 
 int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int Z, int Y, int X, int C,
-                     const double *alpha3, int iterations, int update_lag, const double *a_data, double hx,
-                     double hy, double hz, int solver_fp64, float *duvw_out)
+                     const double *alpha3, int iterations, int update_lag, const double *a_data, double a_smooth,
+                     double hx, double hy, double hz, int solver_fp64, float *duvw_out)
 {
     FR3D_TRY
     ensure_init();
@@ -1131,7 +1168,33 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     FR3D_HIP(hipMemsetAsync(db, 0, ns * 3 * 4, e.st));
     a.iterations = iterations;
     a.update_lag = update_lag;
-    launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
+    if (a_smooth == 1.0) {
+        launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
+    } else {
+        float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);
+        SmoothArgs<float> sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.view.Z = Z; sa.view.Y = Y; sa.view.X = X; sa.view.Yp = sk.Yp; sa.view.plane = sk.plane;
+        sa.view.hx = hx; sa.view.hy = hy; sa.view.hz = hz; sa.view.a_smooth = a_smooth;
+        launch_skew_copy_n<float, float>(e.st, dU, (long long)n, smU, (long long)ns, 3, sk);
+        FR3D_HIP(hipMemsetAsync(smD, 0, ns * 9 * 4, e.st));
+        for (int d = 0; d < 3; d++) {
+            sa.view.U[d] = smU + (size_t)d * ns;
+            for (int q = 0; q < 3; q++) sa.D[q][d] = smD + ((size_t)q * 3 + d) * ns;
+        }
+        sa.Ps = smP;
+        for (int q = 0; q < 9; q++) sa.M[q] = a.M[q];
+        for (int c = 0; c < C; c++) {
+            for (int q = 0; q < 12; q++) sa.A[q * FR3D_MAX_CHANNELS + c] = a.A[q * FR3D_MAX_CHANNELS + c];
+            sa.weight[c] = a.weight[c];
+            sa.a_data[c] = a_data[c];
+        }
+        sa.ax = a.ax; sa.ay = a.ay; sa.az = a.az;
+        sa.C = C; sa.iterations = iterations; sa.update_lag = update_lag; sa.S_planes = sk.S;
+        launch_sor_smooth<float>(e.st, sa);
+        if (iterations > 0)
+            FR3D_HIP(hipMemcpyAsync(db, sa.D[(iterations - 1) % 3][0], ns * 3 * 4, hipMemcpyDeviceToDevice, e.st));
+    }
     launch_unskew_copy_n<float, float>(e.st, db, (long long)ns, dn, (long long)n, 3, sk);
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 4, hipMemcpyDeviceToHost));

@@ -100,6 +100,34 @@ struct SorArgsT {
 };
 using SorArgs = SorArgsT<float>;
 
+// ---- a_smooth != 1 solver path (k_sor_smooth.hip) ------------------------------------------------
+#define SM_LAG 4  // hyperplanes between consecutive in-flight iterations on this path
+template <typename S>
+struct SmoothView {
+    const S *U[3];   // u,v,w skewed (interior)
+    const S *Dm1[3]; // increments of iteration t-1
+    const S *Dm2[3]; // increments of iteration t-2 (ghost source)
+    int Z, Y, X, Yp;
+    long long plane;
+    double hx, hy, hz, a_smooth;
+};
+
+template <typename S>
+struct SmoothArgs {
+    SmoothView<S> view;      // U + geometry; Dm1/Dm2 are set per launch from `D`
+    S *D[3][3];              // [buffer][component], iteration t writes D[t % 3]
+    S *Ps;                   // psi_s of the iteration that will sweep next (in place per plane)
+    S *M[9];                 // frozen data-term system (M11,M22,M33,M12,M13,M23, b_u,b_v,b_w; b without L)
+    const S *A[12 * FR3D_MAX_CHANNELS];
+    const S *weight[FR3D_MAX_CHANNELS];
+    double ax, ay, az;
+    double a_data[FR3D_MAX_CHANNELS];
+    int C, iterations, update_lag, S_planes;
+};
+
+template <typename S>
+long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a);
+
 // ---- launchers (each enqueues on `st`, no synchronisation) ------------------------------------
 
 // K1 resample: one separable pass.  src element (a,b,c) at ((a*n1+b)*n2+c)*cs+co ; dst planar.

@@ -128,11 +128,9 @@ class HipExecutor3D:
         # get_displacement's own defaults (core/optical_flow_3d.py:319-333) for missing keys
         alpha = fp.get("alpha", (2, 2, 2))
         a_smooth = float(fp.get("a_smooth", 0.5))
-        if a_smooth != 1.0:
-            raise NotImplementedError("a_smooth != 1.0 is not implemented on the device yet")
         params = _lib.make_params(alpha, fp.get("update_lag", 10), fp.get("iterations", 20),
                                   fp.get("min_level", 0), fp.get("levels", 50), fp.get("eta", 0.8), a_smooth,
-                                  fp.get("a_data", 0.45), nc, bool(fp.get("solver_fp64", False)))
+                                  fp.get("a_data", 0.45), nc, int(fp.get("solver_fp64", 0)))
         wt = expand_weight(fp.get("weight", None), Z, Y, X, nc)
 
         def f32(a, shape):

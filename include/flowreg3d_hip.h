@@ -44,7 +44,8 @@ typedef struct fr3d_params {
     int min_level;
     int levels;
     double eta;
-    double a_smooth;                   /* only 1.0 is implemented on the device */
+    double a_smooth;                   /* 1.0: constant diffusion (fast path); otherwise psi_smooth is
+                                          re-evaluated every iteration (k_sor_smooth.hip) */
     double a_data[FR3D_MAX_CHANNELS];  /* per channel */
     int solver_fp64;                   /* 0: fp32 storage + fp32 update arithmetic (default);
                                           1: fp32 storage, fp64 update arithmetic;
@@ -139,15 +140,15 @@ int fr3d_resize3d(const float *src, int D, int H, int W, int od, int oh, int ow,
 int fr3d_motion_tensor(const float *f1, const float *f2, int Z, int Y, int X, double hz,
                        double hy, double hx, float *J, float *A);
 
-/* level_solver -> compute_flow_3d (core/level_solver_3d.py:314-546), a_smooth == 1.
+/* level_solver -> compute_flow_3d (core/level_solver_3d.py:314-546).
  * A: (12,C,Z,Y,X) fp32 square-root factors of the motion tensor as fr3d_motion_tensor returns
  * them (J = sum_k a_k a_k^T; the solver rebuilds the tensor entries from them);
  * weight: (C,Z,Y,X) fp32; uvw: (3,Z,Y,X) fp32 interior flow (ghosts are the edge pad of
  * optical_flow_3d.py:88); duvw_out: (3,Z,Y,X) fp32 interior increments. */
 int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int Z, int Y, int X,
                      int C, const double *alpha3, int iterations, int update_lag,
-                     const double *a_data, double hx, double hy, double hz, int solver_fp64,
-                     float *duvw_out);
+                     const double *a_data, double a_smooth, double hx, double hy, double hz,
+                     int solver_fp64, float *duvw_out);
 
 /* scipy.ndimage.median_filter(size=5^3, mode="mirror") (core/optical_flow_3d.py:517-526). */
 int fr3d_median5(const float *in, int Z, int Y, int X, float *out);

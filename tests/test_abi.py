@@ -66,7 +66,7 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
         pytest.skip("a GPU is visible")
     z = np.zeros((8, 8, 8), np.float32)
     with pytest.raises(RuntimeError):
-        flowreg3d_amd.get_displacement(z, z, a_smooth=1.0)
+        flowreg3d_amd.get_displacement(z, z)
     with pytest.raises(RuntimeError):
         flowreg3d_amd.imregister_wrapper(z, z, z, z, z)
     from flowreg3d_amd.executor import HipExecutor3D

@@ -42,10 +42,27 @@ def test_flow_vs_oracle_cfg1_full_iterations(hip, oracle, fp64):
     assert mean < EPE_MEAN_TOL, (mean, mx)
 
 
-def test_a_smooth_not_one_is_refused(hip):
-    z = np.zeros((8, 8, 8), np.float32)
-    with pytest.raises(NotImplementedError):
-        hip.get_displacement(z, z, a_smooth=0.5)
+def test_a_smooth_half_vs_reference_golden(hip):
+    """a_smooth != 1 (psi_smooth every iteration) -- get_displacement's own default."""
+    g = golden("e2e_asmooth")
+    kw = params_of(g)
+    assert kw["a_smooth"] == 0.5
+    for mode, tol in ((0, 1e-4), (2, 2e-5)):
+        flow = hip.get_displacement(g["fixed"], g["moving"], solver_fp64=mode, **kw)
+        mean, mx = _epe(flow, g["flow"])
+        print(f"e2e_asmooth mode {mode}: EPE vs reference mean {mean:.3e} max {mx:.3e}")
+        assert mean < tol, (mode, mean, mx)
+
+
+def test_default_arguments_run_like_the_reference(hip, oracle):
+    # get_displacement(fixed, moving) with every default (alpha 2, lag 10, 20 iterations, a_smooth 0.5)
+    from flowreg3d_amd.synthetic import make_pair
+    fixed, moving, _ = make_pair((16, 24, 24), seed=8, scale=0.5)
+    want = oracle.get_displacement(fixed, moving)
+    got = hip.get_displacement(fixed, moving)
+    mean, mx = _epe(got, want)
+    print(f"defaults: EPE vs oracle mean {mean:.3e} max {mx:.3e}")
+    assert mean < EPE_MEAN_TOL, (mean, mx)
 
 
 def test_two_channel_expansion_rotation_vs_oracle(hip, oracle):

@@ -114,6 +114,17 @@ def test_level_solver_vs_reference_golden(hip, case, it, lag, ad, fp64):
     assert err < (2e-5 if fp64 else 5e-5) * max(scale, 1.0), err
 
 
+def test_level_solver_a_smooth_vs_reference_golden(hip):
+    g = golden("k7_solver")
+    hx, hy, hz = g["h"]
+    du, dv, dw = hip.level_solver(*list(g["J_c1"]), g["wt_c1"], g["u"], g["v"], g["w"], (0.25, 0.3, 0.35), 6, 2, 0,
+                                  np.array([0.45]), 0.5, hx, hy, hz)
+    want = g["c1_a045_s05"]
+    inner = (slice(1, -1),) * 3
+    err = max(np.abs(d[inner] - want[..., k][inner]).max() for k, d in enumerate((du, dv, dw)))
+    assert err < 5e-5 * max(np.abs(want).max(), 1.0), err
+
+
 def test_level_solver_matches_oracle_bigger(hip, oracle):
     # a larger level, 40 iterations: wavefront pipelining of many in-flight iterations
     from flowreg3d_amd.synthetic import make_pair

@@ -78,8 +78,6 @@ def test_argument_validation_happens_before_the_device():
     z = np.zeros((8, 8, 8), np.float32)
     with pytest.raises(ValueError):
         fr.imregister_wrapper(z, z, z, z, z, "spline")  # same message/exception as the reference
-    with pytest.raises(NotImplementedError):
-        fr.get_displacement(z, z)  # a_smooth defaults to 0.5 like the reference's signature
     with pytest.raises(ValueError):
         fr.get_displacement(z, np.zeros((8, 8, 9), np.float32), a_smooth=1.0)
     with pytest.raises(ValueError):
@@ -108,8 +106,6 @@ def test_executor_rejects_unsupported_requests_without_gpu():
     w = np.zeros((6, 6, 6, 3), np.float32)
     with pytest.raises(ValueError):
         ex.process_batch(b, b, r, r, w, None, None, interpolation_method="bogus", flow_params={"a_smooth": 1.0})
-    with pytest.raises(NotImplementedError):
-        ex.process_batch(b, b, r, r, w, None, None, flow_params={"a_smooth": 0.5})
     with pytest.raises(NotImplementedError):
         ex.process_batch(b, b, r, r, w, None, None, flow_params={"a_smooth": 1.0, "cc_initialization": True})
 
