@@ -246,6 +246,18 @@ def main():
         e2e("e2e_minlevel", (16, 24, 24), 1, (1.2, -0.7, 0.5), dict(base, iterations=10, min_level=1))
     if want("e2e_asmooth"):
         e2e("e2e_asmooth", (12, 16, 16), 1, (0.8, -0.5, 0.3), dict(base, iterations=6, a_smooth=0.5, alpha=(2, 2, 2)))
+    if want("e2e_cfg5like"):
+        # reduced BASELINE config 5: two channels (weights 0.5/0.5), expansion/contraction + rotations,
+        # synthetic pair from the build's own generator (flowreg3d_amd/synthetic.py)
+        sys.path.insert(0, ROOT)
+        from flowreg3d_amd.synthetic import make_pair
+        fixed, moving, _ = make_pair((24, 48, 48), seed=1234, channels=2, motion="expansion", scale=1.0)
+        kw = dict(base, iterations=60, levels=4, weight=np.array([0.5, 0.5]))
+        t0 = time.time()
+        flow = of.get_displacement(fixed, moving, **kw)
+        save("e2e_cfg5like", fixed=fixed, moving=moving, flow=flow, weight=kw["weight"],
+             params=np.array([0.25, 0.25, 0.25, 5, 60, 0, 4, 0.8, 1.0, 0.45]))
+        print(f"    e2e_cfg5like: {time.time() - t0:.1f}s")
     if want("e2e_cfg1"):
         # BASELINE config 1: 32x64x64 (Z,Y,X), levels=2 -> 3 solves; iterations=20 keeps the
         # pure-Python run affordable
