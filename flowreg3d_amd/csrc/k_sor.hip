@@ -25,16 +25,12 @@
 #include <cstdlib>
 
 #include "fr3d_internal.h"
+#include "k_sor_core.h"
 
 namespace fr3d {
 
-#define SOR_OMEGA 1.95
 #define SOR_BX 64
 #define SOR_BY_MAX 4  // rows of a tile = blockDim.y (1, 2 or 4; chosen per level, see sor_tile_rows)
-
-template <typename R> __device__ __forceinline__ R fma_(R a, R b, R c);
-template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
-template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
 
 template <typename R, typename S, int C>
 __global__ void __launch_bounds__(SOR_BX * SOR_BY_MAX)
@@ -67,113 +63,28 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
 
     const size_t c0 = (size_t)((long long)s * plane + (long long)k * Yp + jj);
     const long long d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
-    const size_t oM = c0 + (size_t)(vol * a.vsM), oA = c0 + (size_t)(vol * a.vsA), oL = c0 + (size_t)(vol * a.vsL);
     S *const dU = a.d[0] + vol * a.vsD, *const dV = a.d[1] + vol * a.vsD, *const dW = a.d[2] + vol * a.vsD;
     const R du0 = (R)dU[c0], dv0 = (R)dV[c0], dw0 = (R)dW[c0];
 
-    // neighbour sums; a ghost neighbour holds the voxel's own old value (set_boundary_3d)
-    R su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z;
+    // neighbour sums; a ghost neighbour holds the voxel's own old value (set_boundary_3d): a missing
+    // neighbour re-reads c0 (not yet overwritten), so all 18 loads are unconditional and go out
+    // together instead of hiding behind exec-mask branches that wait for du0
     const bool nonb = a.dbg & 1;
-    {
-        const bool hm = i > 0 && !nonb, hp = i < X - 1 && !nonb;
-        const size_t m = (size_t)((long long)c0 - plane + d1), p = (size_t)((long long)c0 + plane + d2);
-        su_x = (hm ? (R)dU[m] : du0) + (hp ? (R)dU[p] : du0);
-        sv_x = (hm ? (R)dV[m] : dv0) + (hp ? (R)dV[p] : dv0);
-        sw_x = (hm ? (R)dW[m] : dw0) + (hp ? (R)dW[p] : dw0);
-    }
-    {
-        const bool hm = j > 0 && !nonb, hp = j < Y - 1 && !nonb;
-        const size_t m = (size_t)((long long)c0 - plane + d1 - 1), p = (size_t)((long long)c0 + plane + d2 + 1);
-        su_y = (hm ? (R)dU[m] : du0) + (hp ? (R)dU[p] : du0);
-        sv_y = (hm ? (R)dV[m] : dv0) + (hp ? (R)dV[p] : dv0);
-        sw_y = (hm ? (R)dW[m] : dw0) + (hp ? (R)dW[p] : dw0);
-    }
-    {
-        const bool hm = k > 0 && !nonb, hp = k < Z - 1 && !nonb;
-        const size_t m = c0 - (size_t)plane - Yp, p = c0 + (size_t)plane + Yp;
-        su_z = (hm ? (R)dU[m] : du0) + (hp ? (R)dU[p] : du0);
-        sv_z = (hm ? (R)dV[m] : dv0) + (hp ? (R)dV[p] : dv0);
-        sw_z = (hm ? (R)dW[m] : dw0) + (hp ? (R)dW[p] : dw0);
-    }
-    // System of this voxel for the current psi window: M = sum_c w_c psi_c J_c (6 entries of the
-    // symmetric 3x3 block) and b = L - sum_c w_c psi_c (J14,J24,J34)_c.  psi is frozen between
-    // psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration
-    // builds them from the factors and stores them, the other iterations just stream the 9 values
-    // -- independent of the channel count.
-    R M11, M22, M33, M12, M13, M23, b_u, b_v, b_w;
+    const size_t xm = (i > 0 && !nonb) ? (size_t)((long long)c0 - plane + d1) : c0;
+    const size_t xp = (i < X - 1 && !nonb) ? (size_t)((long long)c0 + plane + d2) : c0;
+    const size_t ym = (j > 0 && !nonb) ? (size_t)((long long)c0 - plane + d1 - 1) : c0;
+    const size_t yp = (j < Y - 1 && !nonb) ? (size_t)((long long)c0 + plane + d2 + 1) : c0;
+    const size_t zm = (k > 0 && !nonb) ? c0 - (size_t)plane - Yp : c0;
+    const size_t zp = (k < Z - 1 && !nonb) ? c0 + (size_t)plane + Yp : c0;
+    const R su_x = (R)dU[xm] + (R)dU[xp], sv_x = (R)dV[xm] + (R)dV[xp], sw_x = (R)dW[xm] + (R)dW[xp];
+    const R su_y = (R)dU[ym] + (R)dU[yp], sv_y = (R)dV[ym] + (R)dV[yp], sw_y = (R)dW[ym] + (R)dW[yp];
+    const R su_z = (R)dU[zm] + (R)dU[zp], sv_z = (R)dV[zm] + (R)dV[zp], sw_z = (R)dW[zm] + (R)dW[zp];
+    R m[9];
     const bool upd = (t % a.update_lag) == 0 && !(a.dbg & 4);
-    if (upd) {
-        M11 = M22 = M33 = M12 = M13 = M23 = (R)0;
-        R bu = 0, bv = 0, bw = 0;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            // psi_data update (level_solver_3d.py:356-377) from the increments of iteration t-1.
-            // The quadratic form is evaluated as the sum of three squared residuals of the tensor's
-            // square-root factors (see k_tensor.hip) -- algebraically the reference's expression,
-            // but stable with fp32 storage.
-            S f[12];
-#pragma unroll
-            for (int q = 0; q < 12; q++) f[q] = a.A[q * FR3D_MAX_CHANNELS + c][oA];
-            double wt = (double)a.weight[c][c0];
-            const double adc = a.a_data[c];
-            if (adc != 1.0) {
-                const double u_ = (double)du0, v_ = (double)dv0, w_ = (double)dw0;
-                double val = 0.0;
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    double r = fma((double)f[4 * k], u_, fma((double)f[4 * k + 1], v_,
-                                   fma((double)f[4 * k + 2], w_, (double)f[4 * k + 3])));
-                    val = fma(r, r, val);
-                }
-                // fp32 powf (~1 ulp): the products below are stored in fp32 anyway, and the fp64
-                // pow's ~600-instruction dependent chain set a ~6 us latency floor on every launch
-                if (sizeof(S) == 8) wt *= adc * pow(val + 1e-6, adc - 1.0);  // reference-grade mode
-                else wt *= adc * (double)powf((float)(val + 1e-6), (float)(adc - 1.0));
-            }
-            const R w = (R)(S)wt;
-            const R x0 = (R)f[0], x1 = (R)f[1], x2 = (R)f[2], x3 = (R)f[3];
-            const R y0 = (R)f[4], y1 = (R)f[5], y2 = (R)f[6], y3 = (R)f[7];
-            const R z0 = (R)f[8], z1 = (R)f[9], z2 = (R)f[10], z3 = (R)f[11];
-            M11 = fma_<R>(w, fma_<R>(z0, z0, fma_<R>(y0, y0, x0 * x0)), M11);
-            M22 = fma_<R>(w, fma_<R>(z1, z1, fma_<R>(y1, y1, x1 * x1)), M22);
-            M33 = fma_<R>(w, fma_<R>(z2, z2, fma_<R>(y2, y2, x2 * x2)), M33);
-            M12 = fma_<R>(w, fma_<R>(z0, z1, fma_<R>(y0, y1, x0 * x1)), M12);
-            M13 = fma_<R>(w, fma_<R>(z0, z2, fma_<R>(y0, y2, x0 * x2)), M13);
-            M23 = fma_<R>(w, fma_<R>(z1, z2, fma_<R>(y1, y2, x1 * x2)), M23);
-            bu = fma_<R>(w, fma_<R>(z0, z3, fma_<R>(y0, y3, x0 * x3)), bu);
-            bv = fma_<R>(w, fma_<R>(z1, z3, fma_<R>(y1, y3, x1 * x3)), bv);
-            bw = fma_<R>(w, fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3)), bw);
-        }
-        b_u = (R)a.L[0][oL] - bu;
-        b_v = (R)a.L[1][oL] - bv;
-        b_w = (R)a.L[2][oL] - bw;
-        a.M[0][oM] = (S)M11; a.M[1][oM] = (S)M22; a.M[2][oM] = (S)M33;
-        a.M[3][oM] = (S)M12; a.M[4][oM] = (S)M13; a.M[5][oM] = (S)M23;
-        a.M[6][oM] = (S)b_u; a.M[7][oM] = (S)b_v; a.M[8][oM] = (S)b_w;
-        // use the stored (rounded) values so update and non-update iterations see one system
-        M11 = (R)(S)M11; M22 = (R)(S)M22; M33 = (R)(S)M33;
-        M12 = (R)(S)M12; M13 = (R)(S)M13; M23 = (R)(S)M23;
-        b_u = (R)(S)b_u; b_v = (R)(S)b_v; b_w = (R)(S)b_w;
-    } else {
-        M11 = (R)a.M[0][oM]; M22 = (R)a.M[1][oM]; M33 = (R)a.M[2][oM];
-        M12 = (R)a.M[3][oM]; M13 = (R)a.M[4][oM]; M23 = (R)a.M[5][oM];
-        b_u = (R)a.M[6][oM]; b_v = (R)a.M[7][oM]; b_w = (R)a.M[8][oM];
-    }
-    const R ax = (R)a.ax, ay = (R)a.ay, az = (R)a.az;
-    const R num_u = fma_<R>(az, su_z, fma_<R>(ay, su_y, fma_<R>(ax, su_x, b_u)));
-    const R num_v = fma_<R>(az, sv_z, fma_<R>(ay, sv_y, fma_<R>(ax, sv_x, b_v)));
-    const R num_w = fma_<R>(az, sw_z, fma_<R>(ay, sw_y, fma_<R>(ax, sw_x, b_w)));
-    const R diag = (R)(2.0 * a.ax + 2.0 * a.ay + 2.0 * a.az);
-    const R den_u = diag + M11, den_v = diag + M22, den_w = diag + M33;
-
-    const R om = (R)SOR_OMEGA, om1 = (R)(1.0 - SOR_OMEGA);
-    // du (uses old dv, dw), dv (new du, old dw), dw (new du, dv): level_solver_3d.py:503-540
-    R n2 = num_u - fma_<R>(M13, dw0, M12 * dv0);
-    const R du1 = fma_<R>(om, (den_u != (R)0 ? n2 / den_u : (R)0), om1 * du0);
-    n2 = num_v - fma_<R>(M23, dw0, M12 * du1);
-    const R dv1 = fma_<R>(om, (den_v != (R)0 ? n2 / den_v : (R)0), om1 * dv0);
-    n2 = num_w - fma_<R>(M23, dv1, M13 * du1);
-    const R dw1 = fma_<R>(om, (den_w != (R)0 ? n2 / den_w : (R)0), om1 * dw0);
+    sor_system<R, S, C, size_t>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
+    R du1, dv1, dw1;
+    sor_relax<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,
+                 dw1);
 
     dU[c0] = (S)du1;
     dV[c0] = (S)dv1;

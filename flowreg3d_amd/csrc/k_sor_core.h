@@ -1,0 +1,110 @@
+// k_sor_core.h -- the per-voxel arithmetic of the a_smooth == 1 SOR sweep, shared by the
+// one-hyperplane kernel (k_sor.hip) and the two-hyperplane band kernel (k_sor_band.hip) so both
+// produce bit-identical increments.  Reference: core/level_solver_3d.py:356-377 (psi_data),
+// :472-493 (stencil), :503-540 (du -> dv -> dw relaxation with omega = 1.95).
+#pragma once
+
+#include "fr3d_internal.h"
+
+namespace fr3d {
+
+#define SOR_OMEGA 1.95
+
+template <typename R> __device__ __forceinline__ R fma_(R a, R b, R c);
+template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
+
+// The 3x3 system of one voxel for the current psi window: m[0..5] = M11,M22,M33,M12,M13,M23 with
+// M = sum_c w_c psi_c J_c, m[6..8] = b = L - sum_c w_c psi_c (J14,J24,J34)_c.  psi is frozen between
+// psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration (`upd`)
+// builds them from the square-root factors and, when `store`, writes them; the other iterations
+// stream the 9 stored values -- independent of the channel count.  `e` is the voxel's element
+// offset inside one volume's array, vM/vA/vL the (wave-uniform) offsets of the volume's slab: the
+// split keeps the per-lane part 32 bits wide so loads take the scalar-base + vector-offset form.
+template <typename R, typename S, int C, typename I>
+__device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool store, long long vM, long long vA,
+                                           long long vL, I e, R du0, R dv0, R dw0, R (&m)[9])
+{
+    if (upd) {
+        R M11 = 0, M22 = 0, M33 = 0, M12 = 0, M13 = 0, M23 = 0, bu = 0, bv = 0, bw = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            // psi_data update (level_solver_3d.py:356-377) from the increments of iteration t-1.
+            // The quadratic form is evaluated as the sum of three squared residuals of the tensor's
+            // square-root factors (see k_tensor.hip) -- algebraically the reference's expression,
+            // but stable with fp32 storage.
+            S f[12];
+#pragma unroll
+            for (int q = 0; q < 12; q++) f[q] = (a.A[q * FR3D_MAX_CHANNELS + c] + vA)[e];
+            double wt = (double)a.weight[c][e];
+            const double adc = a.a_data[c];
+            if (adc != 1.0) {
+                const double u_ = (double)du0, v_ = (double)dv0, w_ = (double)dw0;
+                double val = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double r = fma((double)f[4 * k], u_, fma((double)f[4 * k + 1], v_,
+                                   fma((double)f[4 * k + 2], w_, (double)f[4 * k + 3])));
+                    val = fma(r, r, val);
+                }
+                // fp32 powf (~1 ulp): the products below are stored in fp32 anyway, and the fp64
+                // pow's ~600-instruction dependent chain set a ~6 us latency floor on every launch
+                if (sizeof(S) == 8) wt *= adc * pow(val + 1e-6, adc - 1.0);  // reference-grade mode
+                else wt *= adc * (double)powf((float)(val + 1e-6), (float)(adc - 1.0));
+            }
+            const R w = (R)(S)wt;
+            const R x0 = (R)f[0], x1 = (R)f[1], x2 = (R)f[2], x3 = (R)f[3];
+            const R y0 = (R)f[4], y1 = (R)f[5], y2 = (R)f[6], y3 = (R)f[7];
+            const R z0 = (R)f[8], z1 = (R)f[9], z2 = (R)f[10], z3 = (R)f[11];
+            M11 = fma_<R>(w, fma_<R>(z0, z0, fma_<R>(y0, y0, x0 * x0)), M11);
+            M22 = fma_<R>(w, fma_<R>(z1, z1, fma_<R>(y1, y1, x1 * x1)), M22);
+            M33 = fma_<R>(w, fma_<R>(z2, z2, fma_<R>(y2, y2, x2 * x2)), M33);
+            M12 = fma_<R>(w, fma_<R>(z0, z1, fma_<R>(y0, y1, x0 * x1)), M12);
+            M13 = fma_<R>(w, fma_<R>(z0, z2, fma_<R>(y0, y2, x0 * x2)), M13);
+            M23 = fma_<R>(w, fma_<R>(z1, z2, fma_<R>(y1, y2, x1 * x2)), M23);
+            bu = fma_<R>(w, fma_<R>(z0, z3, fma_<R>(y0, y3, x0 * x3)), bu);
+            bv = fma_<R>(w, fma_<R>(z1, z3, fma_<R>(y1, y3, x1 * x3)), bv);
+            bw = fma_<R>(w, fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3)), bw);
+        }
+        const R b_u = (R)(a.L[0] + vL)[e] - bu;
+        const R b_v = (R)(a.L[1] + vL)[e] - bv;
+        const R b_w = (R)(a.L[2] + vL)[e] - bw;
+        if (store) {
+            (a.M[0] + vM)[e] = (S)M11; (a.M[1] + vM)[e] = (S)M22; (a.M[2] + vM)[e] = (S)M33;
+            (a.M[3] + vM)[e] = (S)M12; (a.M[4] + vM)[e] = (S)M13; (a.M[5] + vM)[e] = (S)M23;
+            (a.M[6] + vM)[e] = (S)b_u; (a.M[7] + vM)[e] = (S)b_v; (a.M[8] + vM)[e] = (S)b_w;
+        }
+        // use the stored (rounded) values so update and non-update iterations see one system
+        m[0] = (R)(S)M11; m[1] = (R)(S)M22; m[2] = (R)(S)M33;
+        m[3] = (R)(S)M12; m[4] = (R)(S)M13; m[5] = (R)(S)M23;
+        m[6] = (R)(S)b_u; m[7] = (R)(S)b_v; m[8] = (R)(S)b_w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 9; q++) m[q] = (R)(a.M[q] + vM)[e];
+    }
+}
+
+// One relaxation of the voxel: s?_x/y/z are the sums of the two neighbour increments along each
+// axis (a ghost neighbour contributes the voxel's own old value, set_boundary_3d :246-259).
+// du uses old dv,dw; dv uses new du, old dw; dw uses new du,dv (level_solver_3d.py:503-540).
+template <typename R>
+__device__ __forceinline__ void sor_relax(const R (&m)[9], double axd, double ayd, double azd, R su_x, R sv_x,
+                                          R sw_x, R su_y, R sv_y, R sw_y, R su_z, R sv_z, R sw_z, R du0, R dv0,
+                                          R dw0, R &du1, R &dv1, R &dw1)
+{
+    const R ax = (R)axd, ay = (R)ayd, az = (R)azd;
+    const R num_u = fma_<R>(az, su_z, fma_<R>(ay, su_y, fma_<R>(ax, su_x, m[6])));
+    const R num_v = fma_<R>(az, sv_z, fma_<R>(ay, sv_y, fma_<R>(ax, sv_x, m[7])));
+    const R num_w = fma_<R>(az, sw_z, fma_<R>(ay, sw_y, fma_<R>(ax, sw_x, m[8])));
+    const R diag = (R)(2.0 * axd + 2.0 * ayd + 2.0 * azd);
+    const R den_u = diag + m[0], den_v = diag + m[1], den_w = diag + m[2];
+    const R om = (R)SOR_OMEGA, om1 = (R)(1.0 - SOR_OMEGA);
+    R n2 = num_u - fma_<R>(m[4], dw0, m[3] * dv0);
+    du1 = fma_<R>(om, (den_u != (R)0 ? n2 / den_u : (R)0), om1 * du0);
+    n2 = num_v - fma_<R>(m[5], dw0, m[3] * du1);
+    dv1 = fma_<R>(om, (den_v != (R)0 ? n2 / den_v : (R)0), om1 * dv0);
+    n2 = num_w - fma_<R>(m[5], dv1, m[4] * du1);
+    dw1 = fma_<R>(om, (den_w != (R)0 ? n2 / den_w : (R)0), om1 * dw0);
+}
+
+}  // namespace fr3d
