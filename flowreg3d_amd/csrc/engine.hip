@@ -211,15 +211,13 @@ struct Engine {
     hipStream_t st = nullptr;
     std::map<std::string, DevBuf> bufs;
     std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
-    std::map<std::tuple<int, int, int, int, int>, SorSched> scheds;  // (Z,Y,X,iterations,kernel) of a level
+    std::map<std::tuple<int, int, int, int>, SorSched> scheds;     // (Z,Y,X,iterations) of a level
 
-    const SorSched &sched(const Skew &sk, int iterations, int band = 0)
+    const SorSched &sched(const Skew &sk, int iterations)
     {
-        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, band);
+        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations);
         auto it = scheds.find(key);
-        if (it == scheds.end())
-            it = scheds.emplace(key, band ? build_band_schedule(sk, iterations)
-                                          : build_sor_schedule(sk, iterations, sor_tile_rows(sk))).first;
+        if (it == scheds.end()) it = scheds.emplace(key, build_sor_schedule(sk, iterations, sor_tile_rows(sk))).first;
         return it->second;
     }
     // profiling
@@ -417,8 +415,6 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         S *wsk = (S *)e.bufs["w_sk" + sn].ensure(ns * C * sizeof(S));
         S *Lbuf = (S *)e.bufs["L_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
         S *dbuf = (S *)e.bufs["d_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
-        const bool band = sizeof(S) == 4 && sor_band_usable(sk, C, p.solver_fp64, p.a_smooth);
-        S *dbuf2 = band ? (S *)e.bufs["d2_sk" + sn].ensure(ns * 3 * nres * sizeof(S)) : nullptr;
         SorArgsT<S> a;
         std::memset(&a, 0, sizeof(a));
         a.sk = sk;
@@ -442,13 +438,11 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         for (int d = 0; d < 3; d++) {
             a.L[d] = Lbuf + (size_t)d * ns;
             a.d[d] = dbuf + (size_t)d * ns;
-            a.d2[d] = band ? dbuf2 + (size_t)d * ns : nullptr;
         }
         {
             Span sp(e, FR3D_K_OTHER, 0, 0, 0);
             launch_skew_copy_n<float, S>(e.st, rp.wl[li], (long long)nl, wsk, (long long)ns, C, sk);
             FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(S), e.st));
-            if (band) FR3D_HIP(hipMemsetAsync(dbuf2, 0, ns * 3 * nb * sizeof(S), e.st));
         }
 
         const std::string sfx = flip ? "_a" : "_b";
@@ -499,16 +493,9 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         }
         a.iterations = p.iterations;
         a.update_lag = p.update_lag;
-        S *dres = dbuf;  // where the level's final increments are
         if (p.a_smooth == 1.0) {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
-            long long n;
-            if (band) {
-                n = launch_sor_band(e.st, *reinterpret_cast<const SorArgsT<float> *>(&a), e.sched(sk, p.iterations, 1));
-                if (sor_band_result(p.iterations)) dres = dbuf2;
-            } else {
-                n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
-            }
+            long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
             sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
         } else {
             // a_smooth != 1 (k_sor_smooth.hip): psi_smooth every iteration, triple-buffered increments,
@@ -558,7 +545,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 Span sp(e, FR3D_K_OTHER, 0, 0, 0);
                 // increments leave the solver rounded to fp32: the next level (and the executor) cast to
                 // fp32 anyway (util/resize_util_3D.py:116, sequential_3d.py:150) and the median commutes with it
-                launch_unskew_copy_n<S, float>(e.st, dres + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
+                launch_unskew_copy_n<S, float>(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
             }
             if (med) {
                 Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);
@@ -1181,14 +1168,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     FR3D_HIP(hipMemsetAsync(db, 0, ns * 3 * 4, e.st));
     a.iterations = iterations;
     a.update_lag = update_lag;
-    float *dres = db;
-    if (sor_band_usable(sk, C, solver_fp64, a_smooth)) {
-        float *db2 = (float *)s.alloc(ns * 3 * 4);
-        FR3D_HIP(hipMemsetAsync(db2, 0, ns * 3 * 4, e.st));
-        for (int d = 0; d < 3; d++) a.d2[d] = db2 + (size_t)d * ns;
-        launch_sor_band(e.st, a, e.sched(sk, iterations, 1));
-        if (sor_band_result(iterations)) dres = db2;
-    } else if (a_smooth == 1.0) {
+    if (a_smooth == 1.0) {
         launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
     } else {
         float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);
@@ -1215,7 +1195,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
         if (iterations > 0)
             FR3D_HIP(hipMemcpyAsync(db, sa.D[(iterations - 1) % 3][0], ns * 3 * 4, hipMemcpyDeviceToDevice, e.st));
     }
-    launch_unskew_copy_n<float, float>(e.st, dres, (long long)ns, dn, (long long)n, 3, sk);
+    launch_unskew_copy_n<float, float>(e.st, db, (long long)ns, dn, (long long)n, 3, sk);
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 4, hipMemcpyDeviceToHost));
     FR3D_CATCH

@@ -86,8 +86,7 @@ struct SorArgsT {
     const S *A[12 * FR3D_MAX_CHANNELS];
     const S *weight[FR3D_MAX_CHANNELS];
     const S *L[3];  // alpha-weighted Laplacian of u,v,w (constant over the iterations)
-    S *d[3];        // du,dv,dw, updated in place (k_sor.hip); even iterations' results (k_sor_band.hip)
-    S *d2[3];       // band kernel only: results of odd iterations (ping-pong partner of d)
+    S *d[3];        // du,dv,dw, updated in place
     Skew sk;
     double ax, ay, az;  // alpha/h^2
     double a_data[FR3D_MAX_CHANNELS];
@@ -192,18 +191,6 @@ void free_sor_schedule(SorSched &s);
 // Runs all `iterations` pipelined hyperplane steps.  Returns the number of kernel launches.
 template <typename S>
 long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorSched &sched);
-
-// Band variant (k_sor_band.hip): every launch advances each in-flight iteration by TWO hyperplanes
-// (the second one fed from LDS), iterations 3 planes apart, increments ping-ponged between a.d and
-// a.d2 (both zeroed by the caller).  Same arithmetic, bit-identical results.  Returns the launch
-// count; the final increments are in a.d when `iterations` is odd or 0, else in a.d2
-// (sor_band_result).
-SorSched build_band_schedule(const Skew &sk, int iterations);
-long long launch_sor_band(hipStream_t st, const SorArgsT<float> &a, const SorSched &sched);
-static inline int sor_band_result(int iterations) { return iterations > 0 ? ((iterations - 1) & 1) : 0; }
-// 0 = one-hyperplane kernel, 1 = band kernel (env FR3D_SOR_KERNEL; default set in k_sor_band.hip)
-int sor_kernel_choice();
-bool sor_band_usable(const Skew &sk, int C, int solver_fp64, double a_smooth);
 
 // K8 median (natural layout)
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);

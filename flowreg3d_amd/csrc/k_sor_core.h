@@ -1,6 +1,5 @@
-// k_sor_core.h -- the per-voxel arithmetic of the a_smooth == 1 SOR sweep, shared by the
-// one-hyperplane kernel (k_sor.hip) and the two-hyperplane band kernel (k_sor_band.hip) so both
-// produce bit-identical increments.  Reference: core/level_solver_3d.py:356-377 (psi_data),
+// k_sor_core.h -- the per-voxel arithmetic of the a_smooth == 1 SOR sweep (k_sor.hip), kept apart
+// from the launch geometry so that alternative sweep kernels reuse it and stay bit-identical.  Reference: core/level_solver_3d.py:356-377 (psi_data),
 // :472-493 (stencil), :503-540 (du -> dv -> dw relaxation with omega = 1.95).
 #pragma once
 
