@@ -86,6 +86,40 @@ def make_pair(shape, seed=1234, channels=1, scale=1.0, cheap=False, motion="rigi
     return np.stack(fs, -1), np.stack(ms, -1), gt
 
 
+def _lerp_shift(vol, shift, axis):
+    """vol sampled at index + shift along one axis, linear interpolation, edge-clamped (O(N))."""
+    n = vol.shape[axis]
+    pos = np.clip(np.arange(n, dtype=np.float64) + shift, 0, n - 1)
+    i0 = np.floor(pos).astype(np.int64)
+    i1 = np.minimum(i0 + 1, n - 1)
+    w = (pos - i0).astype(np.float32)
+    shp = [1, 1, 1]
+    shp[axis] = n
+    w = w.reshape(shp)
+    return np.take(vol, i0, axis=axis) * (1.0 - w) + np.take(vol, i1, axis=axis) * w
+
+
+def fast_pair(shape, shift=(1.7, -1.1, 0.6), seed=1234, block=128):
+    """O(N) stand-in for make_pair at 256^3 / 512^3 test sizes: a periodic blurred-noise block tiled
+    over the volume plus one broad bump (breaks the periodicity), and a pure translation
+    moving(x) = fixed(x - shift) by separable linear interpolation.  -> fixed, moving, flow"""
+    Z, Y, X = shape
+    rng = np.random.Generator(np.random.PCG64(seed))
+    b = min(block, Z, Y, X)
+    base = ndimage.gaussian_filter(rng.random((b, b, b), dtype=np.float32), 2.0, mode="wrap")
+    base = (base - base.min()) / (base.max() - base.min())
+    reps = [-(-n // b) for n in shape]
+    vol = np.tile(base, reps)[:Z, :Y, :X]
+    g = [np.exp(-0.5 * ((np.arange(n, dtype=np.float32) - 0.45 * n) / (0.3 * n)) ** 2) for n in shape]
+    fixed = (0.7 * vol + 0.3 * g[0][:, None, None] * g[1][None, :, None] * g[2][None, None, :]).astype(np.float32)
+    moving = fixed
+    for axis, d in zip((2, 1, 0), shift):  # shift = (dx, dy, dz)
+        moving = _lerp_shift(moving, -d, axis)
+    flow = np.empty(shape + (3,), np.float32)
+    flow[...] = np.asarray(shift, np.float32)
+    return fixed, moving.astype(np.float32), flow
+
+
 def epe(a, b, crop=0):
     """mean / max end-point error between two (Z,Y,X,3) flows, optionally cropped per side."""
     a = np.asarray(a, dtype=np.float64)

@@ -1,0 +1,123 @@
+"""-m gpu: BASELINE.json's full-size configurations (256^3 five-level, 512^3 six-level) through the
+C ABI.  The CPU oracle needs minutes at these sizes, so the checks are the size-independent
+properties the problem offers plus one oracle-linked case per size that exercises the full-size
+resampling / upsampling path with the solver confined to coarse levels (256^3) or the resampler
+alone (512^3):
+
+  * identical volumes            -> exactly zero flow, registered == moving
+  * determinism                  -> two runs are bit-identical
+  * lock-step batch invariance   -> fr3d_process_batch of T volumes == T single calls, bit for bit
+  * ground truth                 -> the known synthetic motion is recovered (interior EPE bound)
+  * warp round trip              -> warping `moving` by the computed flow brings it back to `fixed`
+  * coarse-only solve vs oracle  -> EPE < 1e-4 (the north-star tolerance) on 256^3 inputs
+  * resampler vs oracle          -> bit-exact 512^3 -> coarse level -> 512^3
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SOLVER = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=100, eta=0.8, a_smooth=1.0, a_data=0.45)
+
+
+@pytest.fixture(scope="module")
+def pair512():
+    from flowreg3d_amd.synthetic import fast_pair
+    return fast_pair((512, 512, 512))
+
+
+@pytest.fixture(scope="module")
+def pair256():
+    from flowreg3d_amd.synthetic import fast_pair
+    return fast_pair((256, 256, 256))
+
+
+def _interior(a, m):
+    return a[m:-m, m:-m, m:-m]
+
+
+def test_cfg2_256_properties(hip, pair256):
+    import flowreg3d_amd as fr
+    fixed, moving, gt = pair256
+    kw = dict(SOLVER, min_level=0, levels=4)  # 5-level pyramid
+    flow = fr.get_displacement(fixed, moving, **kw)
+    assert flow.shape == (256, 256, 256, 3) and np.isfinite(flow).all()
+    # determinism
+    again = fr.get_displacement(fixed, moving, **kw)
+    assert np.array_equal(flow, again)
+    # ground truth (translation 1.7/-1.1/0.6 voxels): interior end-point error
+    err = np.linalg.norm(_interior(flow, 24) - _interior(gt, 24), axis=-1)
+    assert err.mean() < 0.08 and np.percentile(err, 99) < 0.5, (err.mean(), np.percentile(err, 99))
+    # warp round trip: moving sampled at x + flow is fixed again (intensities in [0,1])
+    reg = fr.imregister_wrapper(moving, flow[..., 0], flow[..., 1], flow[..., 2], fixed)
+    before = np.abs(_interior(moving, 24) - _interior(fixed, 24)).mean()
+    after = np.abs(_interior(np.asarray(reg).reshape(fixed.shape), 24) - _interior(fixed, 24)).mean()
+    assert after < 0.1 * before, (before, after)
+
+
+def test_cfg2_256_identical_volumes_give_zero_flow(hip, pair256):
+    import flowreg3d_amd as fr
+    fixed = pair256[0]
+    flow = fr.get_displacement(fixed, fixed, **dict(SOLVER, min_level=0, levels=4))
+    assert not flow.any()
+    reg = fr.imregister_wrapper(fixed, flow[..., 0], flow[..., 1], flow[..., 2], fixed)
+    assert np.array_equal(np.asarray(reg).reshape(fixed.shape), fixed)
+
+
+def test_cfg4_lockstep_batch_equals_single_volumes(hip, pair256):
+    """cfg4's per-GPU share: several 256^3 time points against one reference in one call."""
+    import flowreg3d_amd as fr
+    from flowreg3d_amd.executor import HipExecutor3D
+    from flowreg3d_amd.synthetic import fast_pair
+    fixed = pair256[0]
+    vols = [pair256[1]] + [fast_pair(fixed.shape, shift=s)[1] for s in ((0.8, 0.5, -0.3), (-1.2, 0.9, 0.4))]
+    batch = np.stack(vols)[..., None].astype(np.float32)
+    fp = dict(SOLVER, min_level=0, levels=4, iterations=30)
+    w0 = np.zeros(fixed.shape + (3,), np.float32)
+    with HipExecutor3D() as ex:
+        reg, flows = ex.process_batch(batch, batch, fixed[..., None], fixed[..., None], w0, None, None,
+                                      flow_params=fp)
+    for t in range(batch.shape[0]):
+        single = fr.get_displacement(fixed, batch[t, ..., 0], uvw=w0.copy(), **fp).astype(np.float32)
+        assert np.array_equal(flows[t], single), t
+        r = fr.imregister_wrapper(batch[t, ..., 0], single[..., 0], single[..., 1], single[..., 2], fixed)
+        assert np.array_equal(reg[t, ..., 0], np.asarray(r, dtype=np.float32).reshape(fixed.shape)), t
+
+
+def test_cfg2_256_coarse_levels_vs_oracle(hip, oracle, pair256):
+    """Full-size input, solver on the two coarsest levels of the schedule only (84^3, 105^3), 20
+    iterations: the oracle finishes in ~15 s and every full-size resample (fixed, moving, flow
+    upsampling) takes part."""
+    import flowreg3d_amd as fr
+    from flowreg3d_amd.synthetic import epe
+    fixed, moving, _ = pair256
+    kw = dict(SOLVER, min_level=5, levels=5, iterations=20)
+    got = fr.get_displacement(fixed, moving, **kw)
+    want = oracle.get_displacement(fixed, moving, **kw)
+    mean, mx = epe(got, want)
+    assert mean < 1e-4, (mean, mx)
+
+
+def test_cfg3_512_properties(hip, pair512):
+    import flowreg3d_amd as fr
+    fixed, moving, gt = pair512
+    kw = dict(SOLVER, min_level=0, levels=5, iterations=25)  # 6-level pyramid; fewer sweeps keep the test short
+    flow = fr.get_displacement(fixed, moving, **kw)
+    assert flow.shape == (512, 512, 512, 3) and np.isfinite(flow).all()
+    assert np.array_equal(flow, fr.get_displacement(fixed, moving, **kw))
+    err = np.linalg.norm(_interior(flow, 48) - _interior(gt, 48), axis=-1)
+    assert err.mean() < 0.15, err.mean()
+    zero = fr.get_displacement(fixed, fixed, **kw)
+    assert not zero.any()
+
+
+def test_cfg3_512_resampler_vs_oracle(hip, oracle, pair512):
+    """The oracle's whole get_displacement needs >1 min on 512^3 inputs even with the solver confined
+    to coarse levels; the full-size stage that differs from the small-size tests is the resampler
+    (support and tables grow with the scale factor), so that is what is compared here: bit-exact."""
+    import flowreg3d_amd as fr
+    fixed = pair512[0]
+    down = fr.imresize_fused_gauss_cubic3D(fixed, (86, 107, 134))
+    assert np.array_equal(down, oracle.imresize_fused_gauss_cubic3D(fixed, (86, 107, 134)))
+    up = fr.imresize_fused_gauss_cubic3D(down, (512, 512, 512))
+    assert np.array_equal(up, oracle.imresize_fused_gauss_cubic3D(down, (512, 512, 512)))
