@@ -32,7 +32,7 @@ namespace fr3d {
 #define SOR_BX 64
 #define SOR_BY_MAX 4  // rows of a tile = blockDim.y (1, 2 or 4; chosen per level, see sor_tile_rows)
 
-template <typename R, typename S, int C>
+template <typename R, typename S, int C, typename I>
 __global__ void __launch_bounds__(SOR_BX * SOR_BY_MAX)
 k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent)
 {
@@ -61,34 +61,39 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
     const int i = r - j;
     if (r < 0 || j >= Y || i < 0) return;      // i < X holds by construction of jm0
 
-    const size_t c0 = (size_t)((long long)s * plane + (long long)k * Yp + jj);
-    const long long d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
+    // byte offsets (type I, see ldb) of the voxel and of its six neighbours inside one volume's array.
+    // A ghost neighbour holds the voxel's own old value (set_boundary_3d): a missing neighbour
+    // re-reads c0 (not yet overwritten), so all 21 increment loads are unconditional and go out
+    // together instead of hiding behind exec-mask branches that wait for du0.
+    const I esz = (I)sizeof(S);
+    const I c0 = (I)((long long)s * plane + (long long)k * Yp + jj) * esz;
+    const I pl = (I)plane * esz, row = (I)Yp * esz;
+    const I d1 = (I)(jm0 - sk_jm(X, r - 1)) * esz, d2 = (I)(jm0 - sk_jm(X, r + 1)) * esz;  // d2 <= 0: wraps, sums stay exact
     S *const dU = a.d[0] + vol * a.vsD, *const dV = a.d[1] + vol * a.vsD, *const dW = a.d[2] + vol * a.vsD;
-    const R du0 = (R)dU[c0], dv0 = (R)dV[c0], dw0 = (R)dW[c0];
-
-    // neighbour sums; a ghost neighbour holds the voxel's own old value (set_boundary_3d): a missing
-    // neighbour re-reads c0 (not yet overwritten), so all 18 loads are unconditional and go out
-    // together instead of hiding behind exec-mask branches that wait for du0
     const bool nonb = a.dbg & 1;
-    const size_t xm = (i > 0 && !nonb) ? (size_t)((long long)c0 - plane + d1) : c0;
-    const size_t xp = (i < X - 1 && !nonb) ? (size_t)((long long)c0 + plane + d2) : c0;
-    const size_t ym = (j > 0 && !nonb) ? (size_t)((long long)c0 - plane + d1 - 1) : c0;
-    const size_t yp = (j < Y - 1 && !nonb) ? (size_t)((long long)c0 + plane + d2 + 1) : c0;
-    const size_t zm = (k > 0 && !nonb) ? c0 - (size_t)plane - Yp : c0;
-    const size_t zp = (k < Z - 1 && !nonb) ? c0 + (size_t)plane + Yp : c0;
-    const R su_x = (R)dU[xm] + (R)dU[xp], sv_x = (R)dV[xm] + (R)dV[xp], sw_x = (R)dW[xm] + (R)dW[xp];
-    const R su_y = (R)dU[ym] + (R)dU[yp], sv_y = (R)dV[ym] + (R)dV[yp], sw_y = (R)dW[ym] + (R)dW[yp];
-    const R su_z = (R)dU[zm] + (R)dU[zp], sv_z = (R)dV[zm] + (R)dV[zp], sw_z = (R)dW[zm] + (R)dW[zp];
+    const I xm = (i > 0 && !nonb) ? c0 - pl + d1 : c0;
+    const I xp = (i < X - 1 && !nonb) ? c0 + pl + d2 : c0;
+    const I ym = (j > 0 && !nonb) ? c0 - pl + d1 - esz : c0;
+    const I yp = (j < Y - 1 && !nonb) ? c0 + pl + d2 + esz : c0;
+    const I zm = (k > 0 && !nonb) ? c0 - pl - row : c0;
+    const I zp = (k < Z - 1 && !nonb) ? c0 + pl + row : c0;
+    const R du0 = (R)ldb(dU, c0), dv0 = (R)ldb(dV, c0), dw0 = (R)ldb(dW, c0);
+    const R su_x = (R)ldb(dU, xm) + (R)ldb(dU, xp), sv_x = (R)ldb(dV, xm) + (R)ldb(dV, xp),
+            sw_x = (R)ldb(dW, xm) + (R)ldb(dW, xp);
+    const R su_y = (R)ldb(dU, ym) + (R)ldb(dU, yp), sv_y = (R)ldb(dV, ym) + (R)ldb(dV, yp),
+            sw_y = (R)ldb(dW, ym) + (R)ldb(dW, yp);
+    const R su_z = (R)ldb(dU, zm) + (R)ldb(dU, zp), sv_z = (R)ldb(dV, zm) + (R)ldb(dV, zp),
+            sw_z = (R)ldb(dW, zm) + (R)ldb(dW, zp);
     R m[9];
     const bool upd = (t % a.update_lag) == 0 && !(a.dbg & 4);
-    sor_system<R, S, C, size_t>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
+    sor_system<R, S, C, I>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
     R du1, dv1, dw1;
     sor_relax<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,
                  dw1);
 
-    dU[c0] = (S)du1;
-    dV[c0] = (S)dv1;
-    dW[c0] = (S)dw1;
+    stb(dU, c0, (S)du1);
+    stb(dV, c0, (S)dv1);
+    stb(dW, c0, (S)dw1);
 }
 
 template <typename R, typename S>
@@ -96,13 +101,21 @@ static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo,
                         const SorEntry *ent, int by)
 {
     dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, by);
+    // 32-bit byte offsets whenever one volume's array stays below 4 GiB (every BASELINE size does)
+    const bool narrow = (unsigned long long)a.sk.total * sizeof(S) < (1ull << 32);
+#define FR3D_SOR_CASE(CH)                                                                                      \
+    case CH:                                                                                                   \
+        if (narrow) hipLaunchKernelGGL((k_sor_step<R, S, CH, unsigned>), grid, block, 0, st, a, tau, t_lo, nt, ent); \
+        else hipLaunchKernelGGL((k_sor_step<R, S, CH, size_t>), grid, block, 0, st, a, tau, t_lo, nt, ent);     \
+        break;
     switch (a.C) {
-        case 1: hipLaunchKernelGGL((k_sor_step<R, S, 1>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
-        case 2: hipLaunchKernelGGL((k_sor_step<R, S, 2>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
-        case 3: hipLaunchKernelGGL((k_sor_step<R, S, 3>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
-        case 4: hipLaunchKernelGGL((k_sor_step<R, S, 4>), grid, block, 0, st, a, tau, t_lo, nt, ent); break;
+        FR3D_SOR_CASE(1)
+        FR3D_SOR_CASE(2)
+        FR3D_SOR_CASE(3)
+        FR3D_SOR_CASE(4)
         default: throw Error("SOR kernel is instantiated for 1..4 channels");
     }
+#undef FR3D_SOR_CASE
 }
 
 int sor_tile_rows(const Skew &sk)
