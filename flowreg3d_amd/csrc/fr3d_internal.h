@@ -183,8 +183,8 @@ struct SorSched {
     SorEntry *entries = nullptr;                     // device, sum(nt) entries
     int by = 4;                                      // tile rows the schedule was built for
 };
-// Tile = 64 lanes along j x `by` rows.  Measured on MI355X: 4 rows are best up to ~256^3 levels,
-// 2 rows on the long rows of 512^3 levels (+4.5 %); FR3D_SOR_BY overrides.
+// Tile = 64 lanes along j x `by` rows.  Measured on MI355X: 4 rows at every level size (1 and 2 rows
+// are within 2 % since the neighbour loads became unconditional); FR3D_SOR_BY overrides.
 int sor_tile_rows(const Skew &sk);
 SorSched build_sor_schedule(const Skew &sk, int iterations, int by);
 void free_sor_schedule(SorSched &s);

@@ -125,7 +125,8 @@ int sor_tile_rows(const Skew &sk)
         const int v = atoi(env);
         if (v == 1 || v == 2 || v == 4) return v;
     }
-    return (sk.X >= 320 && sk.Y >= 320) ? 2 : 4;
+    (void)sk;
+    return 4;
 }
 
 SorSched build_sor_schedule(const Skew &sk, int T, int by)
