@@ -238,7 +238,8 @@ def main():
                                    "alpha=0.25, a_data=0.45, a_smooth=1; lexicographic-exact SOR",
                        "volumes_per_gpu_per_step": 1, "lockstep_batch": batch_vols,
                        "untimed_conditioning_s": args.condition if W > 0 else 0.0,
-                       "sharding": f"volume-per-GPU x{world}"},
+                       "sharding": f"volume-per-GPU x{world}",
+                       "device": lib.fr3d_device_info().decode()},
             "roofline": {"bound": "hbm", "kernel": "k_sor_step (SOR hyperplane sweep)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -861,6 +861,22 @@ extern "C" {
 const char *fr3d_last_error(void) { return g_err.c_str(); }
 const char *fr3d_version(void) { return "flowreg3d_amd 0.1 (gfx950)"; }
 
+const char *fr3d_device_info(void)
+{
+    static std::string info;
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    info.clear();
+    if (!g_eng.inited) return info.c_str();
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, g_eng.device) != hipSuccess) return info.c_str();
+    char buf[384];
+    snprintf(buf, sizeof(buf), "%s (%s); %d CUs; core %d MHz; memory %d MHz, %d-bit; %.0f GiB", pr.name,
+             pr.gcnArchName, pr.multiProcessorCount, pr.clockRate / 1000, pr.memoryClockRate / 1000,
+             pr.memoryBusWidth, (double)pr.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    info = buf;
+    return info.c_str();
+}
+
 int fr3d_set_batch(int nvol)
 {
     g_batch_hint = nvol > 0 ? nvol : 0;

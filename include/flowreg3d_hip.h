@@ -61,6 +61,9 @@ void fr3d_shutdown(void);               /* frees every device buffer and the str
 const char *fr3d_last_error(void);
 int fr3d_device_count(void);            /* hipGetDeviceCount without initialising a context */
 const char *fr3d_version(void);
+/* One-line description of the initialised device ("name; N CUs; core MHz; memory MHz, bus bits;
+ * GiB") for logs and bench output; "" before fr3d_init. */
+const char *fr3d_device_info(void);
 /* Volumes of a batch that fr3d_process_batch solves in lock step (their SOR launches are shared;
  * default 4, env FR3D_BATCH).  Also reserves solver workspace for that many volumes on first use,
  * so a later full batch does not reallocate.  0 restores the default. */
