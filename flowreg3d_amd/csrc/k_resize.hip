@@ -32,6 +32,30 @@ k_resize_x(const float *__restrict__ src, int cs, int co, long long rows, int n2
             tap[p] = p < P ? ii[p] * cs : 0;
             w[p] = p < P ? ww[p] : 0.0f;
         }
+        if (rpb == RX_ROWS && row0 + RX_ROWS <= rows) {
+            // full group of rows: two rows per trip so that 2P gathers are in flight
+#pragma unroll 1
+            for (int q = 0; q < RX_ROWS; q += 2) {
+                const float *r0 = src + (size_t)(row0 + q) * n2 * cs + co;
+                const float *r1 = r0 + (size_t)n2 * cs;
+                float v0[RX_MAXP], v1[RX_MAXP];
+#pragma unroll
+                for (int p = 0; p < RX_MAXP; p++) {
+                    v0[p] = p < P ? r0[tap[p]] : 0.0f;
+                    v1[p] = p < P ? r1[tap[p]] : 0.0f;
+                }
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int p = 0; p < RX_MAXP; p++)
+                    if (p < P) {  // tap order and fp32 mul/add as the reference
+                        a0 += v0[p] * w[p];
+                        a1 += v1[p] * w[p];
+                    }
+                dst[(size_t)(row0 + q) * out_len + i] = a0;
+                dst[(size_t)(row0 + q + 1) * out_len + i] = a1;
+            }
+            return;
+        }
         for (int q = 0; q < rpb; q++) {
             const long long row = row0 + q;
             if (row >= rows) break;
@@ -54,25 +78,24 @@ k_resize_x(const float *__restrict__ src, int cs, int co, long long rows, int n2
     }
 }
 
-// axis 1 or 0 on planar data: src viewed as (outer, n, inner), dst (outer, out_len, inner)
+// axis 1 or 0 on planar data: src viewed as (outer, n, inner), dst (outer, out_len, inner).
+// blockIdx.y = output index along the axis, blockIdx.z = outer: the P taps and weights of a
+// workgroup are wave-uniform (scalar loads), the P gathers are independent coalesced row reads.
 __global__ void __launch_bounds__(256)
-k_resize_mid(const float *__restrict__ src, long long outer, int n, long long inner, int out_len,
+k_resize_mid(const float *__restrict__ src, int n, long long inner, int out_len,
              const int *__restrict__ idx, const float *__restrict__ wt, int P,
              float *__restrict__ dst)
 {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long total = outer * out_len * inner;
-    if (t >= total) return;
-    long long x = t % inner;
-    long long r = t / inner;
-    int i = (int)(r % out_len);
-    long long o = r / out_len;
+    const long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= inner) return;
+    const int i = blockIdx.y;
+    const long long o = blockIdx.z;
     const float *base = src + (size_t)o * n * inner + x;
     const int *ii = idx + (size_t)i * P;
     const float *ww = wt + (size_t)i * P;
     float a = 0.0f;
-    for (int p = 0; p < P; p++) a += base[(size_t)ii[p] * inner] * ww[p];
-    dst[t] = a;
+    for (int p = 0; p < P; p++) a += base[(size_t)ii[p] * inner] * ww[p];  // tap order as the reference
+    dst[((size_t)o * out_len + i) * inner + x] = a;
 }
 
 void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0, int n1, int n2,
@@ -94,7 +117,9 @@ void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0
         long long inner = (axis == 1) ? n2 : (long long)n1 * n2;
         long long total = outer * out_len * inner;
         if (total == 0) return;
-        hipLaunchKernelGGL(k_resize_mid, dim3(cdiv(total, 256)), dim3(256), 0, st, src, outer, n,
+        FR3D_CHECK(out_len <= 65535 && outer <= 65535, "resize: axis length beyond the grid limits");
+        const int bx = inner >= 256 ? 256 : cdiv(inner, 64) * 64;  // short rows: no idle waves
+        hipLaunchKernelGGL(k_resize_mid, dim3(cdiv(inner, bx), out_len, (unsigned)outer), dim3(bx), 0, st, src, n,
                            inner, out_len, idx, wt, P, dst);
     }
 }
