@@ -48,6 +48,7 @@ template void launch_pad_edge<double>(hipStream_t, const double *, int, int, int
 // ---- 2. prefilter -----------------------------------------------------------------------------
 // One line in place.  `c` points at element 0, consecutive elements are `stride` apart.
 // Same operation order as the CPU restatement: gain folded into the first touch of each sample.
+#define PF_CH 8  // samples fetched per trip: the loads of a trip are independent of the recursion
 __device__ __forceinline__ void spline_line(double *c, int n, long long stride, double z_n)
 {
     const double z = SPL_POLE;
@@ -57,28 +58,57 @@ __device__ __forceinline__ void spline_line(double *c, int n, long long stride, 
     double x0 = c[0] * gain;
     double acc = x0 + z_n * (c[(long long)(n - 1) * stride] * gain);
     double z_i = z;
-    for (int i = 1; i < lim; i++) {
-        double xi = c[(long long)i * stride] * gain;
-        double xr = (i == n - 1) ? acc : c[(long long)(n - 1 - i) * stride] * gain;
-        acc += z_i * (xi + z_n * xr);
-        z_i *= z;
+    for (int i0 = 1; i0 < lim; i0 += PF_CH) {
+        double xi[PF_CH], xr[PF_CH];
+#pragma unroll
+        for (int q = 0; q < PF_CH; q++) {
+            const int i = i0 + q;
+            xi[q] = i < lim ? c[(long long)i * stride] : 0.0;
+            xr[q] = (i < lim && i != n - 1) ? c[(long long)(n - 1 - i) * stride] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < PF_CH; q++) {
+            const int i = i0 + q;
+            if (i < lim) {
+                const double a = xi[q] * gain;
+                const double r = (i == n - 1) ? acc : xr[q] * gain;
+                acc += z_i * (a + z_n * r);
+                z_i *= z;
+            }
+        }
     }
     acc *= z / (1.0 - z_n * z_n);
     acc += x0;
     c[0] = acc;
     double prev = acc;
-    for (int i = 1; i < n; i++) {
-        double xi = c[(long long)i * stride] * gain;
-        xi += z * prev;
-        c[(long long)i * stride] = xi;
-        prev = xi;
+    // causal sweep, PF_CH samples in flight per trip (a thread walks its line alone, and a level has
+    // too few lines to hide one dependent load per sample behind other waves)
+    for (int i0 = 1; i0 < n; i0 += PF_CH) {
+        double v[PF_CH];
+#pragma unroll
+        for (int q = 0; q < PF_CH; q++) v[q] = i0 + q < n ? c[(long long)(i0 + q) * stride] : 0.0;
+#pragma unroll
+        for (int q = 0; q < PF_CH; q++)
+            if (i0 + q < n) {
+                double xi = v[q] * gain;
+                xi += z * prev;
+                c[(long long)(i0 + q) * stride] = xi;
+                prev = xi;
+            }
     }
     prev *= z / (z - 1.0);
     c[(long long)(n - 1) * stride] = prev;
-    for (int i = n - 2; i >= 0; i--) {
-        double v = z * (prev - c[(long long)i * stride]);
-        c[(long long)i * stride] = v;
-        prev = v;
+    for (int i0 = n - 2; i0 >= 0; i0 -= PF_CH) {
+        double v[PF_CH];
+#pragma unroll
+        for (int q = 0; q < PF_CH; q++) v[q] = i0 - q >= 0 ? c[(long long)(i0 - q) * stride] : 0.0;
+#pragma unroll
+        for (int q = 0; q < PF_CH; q++)
+            if (i0 - q >= 0) {
+                const double w = z * (prev - v[q]);
+                c[(long long)(i0 - q) * stride] = w;
+                prev = w;
+            }
     }
 }
 
