@@ -1018,17 +1018,31 @@ int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const floa
     FR3D_CHECK(T >= 0, "T must be >= 0");
     const size_t nv = (size_t)Z * Y * X;
     Staged s;
-    const float *dbp = (const float *)s.up(batch_proc, nv * C * 4 * (size_t)T);
-    const float *dbr = (const float *)s.up(batch_raw, nv * C * 4 * (size_t)T);
     const float *drp = (const float *)s.up(ref_proc, nv * C * 4);
     const float *drr = (const float *)s.up(ref_raw, nv * C * 4);
     const float *dwi = (const float *)s.up(w_init, nv * 3 * 4);
     const float *dwt = (const float *)s.up(weight, nv * C * 4);
-    float *dfl = (float *)s.alloc(nv * 3 * 4 * (size_t)T);
-    float *dre = (float *)s.alloc(nv * C * 4 * (size_t)T);
-    process_batch_dev(p, dbp, dbr, drp, drr, dwi, dwt, T, Z, Y, X, C, order, dfl, dre, progress, user);
-    FR3D_HIP(hipMemcpy(flows_out, dfl, nv * 3 * 4 * (size_t)T, hipMemcpyDeviceToHost));
-    FR3D_HIP(hipMemcpy(registered_out, dre, nv * C * 4 * (size_t)T, hipMemcpyDeviceToHost));
+    // the series passes through the device in windows of whole lock-step batches (<= 16 GiB of
+    // staging), so T is bounded by host memory only
+    const size_t per_vol = nv * 4 * (size_t)(3 * C + 3);
+    const int lock = g_batch_hint > 0 ? g_batch_hint : 4;
+    const char *cap_env = getenv("FR3D_STAGE_KIB");  // staging budget override (tests use it to force windows)
+    const size_t cap = cap_env ? (size_t)std::max(1, atoi(cap_env)) << 10 : (16ull << 30);
+    int win = (int)std::min<size_t>((size_t)std::max(T, 1), std::max<size_t>((size_t)lock, cap / per_vol));
+    win = std::max(lock, win / lock * lock);
+    if (win > T) win = T;
+    float *dbp = (float *)s.alloc(nv * C * 4 * (size_t)win);
+    float *dbr = (float *)s.alloc(nv * C * 4 * (size_t)win);
+    float *dfl = (float *)s.alloc(nv * 3 * 4 * (size_t)win);
+    float *dre = (float *)s.alloc(nv * C * 4 * (size_t)win);
+    for (int t0 = 0; t0 < T; t0 += win) {
+        const int nt = std::min(win, T - t0);
+        FR3D_HIP(hipMemcpy(dbp, batch_proc + (size_t)t0 * nv * C, nv * C * 4 * (size_t)nt, hipMemcpyHostToDevice));
+        FR3D_HIP(hipMemcpy(dbr, batch_raw + (size_t)t0 * nv * C, nv * C * 4 * (size_t)nt, hipMemcpyHostToDevice));
+        process_batch_dev(p, dbp, dbr, drp, drr, dwi, dwt, nt, Z, Y, X, C, order, dfl, dre, progress, user);
+        FR3D_HIP(hipMemcpy(flows_out + (size_t)t0 * nv * 3, dfl, nv * 3 * 4 * (size_t)nt, hipMemcpyDeviceToHost));
+        FR3D_HIP(hipMemcpy(registered_out + (size_t)t0 * nv * C, dre, nv * C * 4 * (size_t)nt, hipMemcpyDeviceToHost));
+    }
     FR3D_CATCH
 }
 

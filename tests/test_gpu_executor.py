@@ -82,3 +82,21 @@ def test_empty_batch(hip):
     fp = dict(alpha=(0.25,) * 3, update_lag=5, iterations=5, min_level=0, levels=2, eta=0.8, a_smooth=1.0, a_data=0.45)
     reg, flows = HipExecutor3D().process_batch(batch[:0], batch[:0], fixed, fixed, w0, None, None, flow_params=fp)
     assert reg.shape[0] == 0 and flows.shape == (0,) + batch.shape[1:4] + (3,)
+
+
+def test_long_series_passes_through_the_device_in_windows(hip, monkeypatch):
+    """fr3d_process_batch stages the series in windows of whole lock-step batches; a 200 KiB budget
+    forces 9 volumes through as 4+4+1 and the result must equal the one-window run bit for bit."""
+    from flowreg3d_amd.executor import HipExecutor3D
+    fixed, batch = _series(T=9, shape=(10, 16, 20))
+    w0 = np.zeros(batch.shape[1:4] + (3,), np.float32)
+    fp = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=10, min_level=0, levels=2, eta=0.8,
+              a_smooth=1.0, a_data=0.45)
+    calls = []
+    with HipExecutor3D() as ex:
+        reg1, fl1 = ex.process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=fp)
+        monkeypatch.setenv("FR3D_STAGE_KIB", "200")
+        reg2, fl2 = ex.process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=fp,
+                                     progress_callback=calls.append)
+    assert sum(calls) == 9
+    assert np.array_equal(fl1, fl2) and np.array_equal(reg1, reg2)
