@@ -4,11 +4,14 @@
 // include/flowreg3d_hip.h.  Everything between the entry copy-in and the exit copy-out stays in
 // HBM; the only host work per level is the (cached) table build and kernel launches.
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -1022,27 +1025,94 @@ int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const floa
     const float *drr = (const float *)s.up(ref_raw, nv * C * 4);
     const float *dwi = (const float *)s.up(w_init, nv * 3 * 4);
     const float *dwt = (const float *)s.up(weight, nv * C * 4);
-    // the series passes through the device in windows of whole lock-step batches (<= 16 GiB of
-    // staging), so T is bounded by host memory only
+    // The series passes through the device in windows of one lock-step batch, double-buffered: a
+    // copier thread uploads window k+2 and downloads window k on its own stream while the engine
+    // stream computes window k+1, so the PCIe traffic (and the page faults of freshly allocated
+    // host output arrays) hide behind the solver.  T is bounded by host memory only.
     const size_t per_vol = nv * 4 * (size_t)(3 * C + 3);
     const int lock = g_batch_hint > 0 ? g_batch_hint : 4;
     const char *cap_env = getenv("FR3D_STAGE_KIB");  // staging budget override (tests use it to force windows)
-    const size_t cap = cap_env ? (size_t)std::max(1, atoi(cap_env)) << 10 : (16ull << 30);
-    int win = (int)std::min<size_t>((size_t)std::max(T, 1), std::max<size_t>((size_t)lock, cap / per_vol));
-    win = std::max(lock, win / lock * lock);
+    const size_t cap = cap_env ? (size_t)std::max(1, atoi(cap_env)) << 10 : (8ull << 30);
+    int win = (int)std::max<size_t>(1, std::min<size_t>((size_t)lock, cap / per_vol));
     if (win > T) win = T;
-    float *dbp = (float *)s.alloc(nv * C * 4 * (size_t)win);
-    float *dbr = (float *)s.alloc(nv * C * 4 * (size_t)win);
-    float *dfl = (float *)s.alloc(nv * 3 * 4 * (size_t)win);
-    float *dre = (float *)s.alloc(nv * C * 4 * (size_t)win);
-    for (int t0 = 0; t0 < T; t0 += win) {
-        const int nt = std::min(win, T - t0);
-        FR3D_HIP(hipMemcpy(dbp, batch_proc + (size_t)t0 * nv * C, nv * C * 4 * (size_t)nt, hipMemcpyHostToDevice));
-        FR3D_HIP(hipMemcpy(dbr, batch_raw + (size_t)t0 * nv * C, nv * C * 4 * (size_t)nt, hipMemcpyHostToDevice));
-        process_batch_dev(p, dbp, dbr, drp, drr, dwi, dwt, nt, Z, Y, X, C, order, dfl, dre, progress, user);
-        FR3D_HIP(hipMemcpy(flows_out + (size_t)t0 * nv * 3, dfl, nv * 3 * 4 * (size_t)nt, hipMemcpyDeviceToHost));
-        FR3D_HIP(hipMemcpy(registered_out + (size_t)t0 * nv * C, dre, nv * C * 4 * (size_t)nt, hipMemcpyDeviceToHost));
+    const int nwin = win > 0 ? cdiv(T, win) : 0;
+    const int nset = nwin > 1 ? 2 : 1;
+    float *dbp[2], *dbr[2], *dfl[2], *dre[2];
+    for (int q = 0; q < nset; q++) {
+        dbp[q] = (float *)s.alloc(nv * C * 4 * (size_t)win);
+        dbr[q] = (float *)s.alloc(nv * C * 4 * (size_t)win);
+        dfl[q] = (float *)s.alloc(nv * 3 * 4 * (size_t)win);
+        dre[q] = (float *)s.alloc(nv * C * 4 * (size_t)win);
     }
+    std::mutex mu;
+    std::condition_variable cv;
+    int uploaded = 0, computed = 0;  // windows finished by each side
+    bool abort_all = false;
+    std::exception_ptr copier_error;
+    const int device = g_eng.device;
+    auto count_of = [&](int k) { return std::min(win, T - k * win); };
+    std::thread copier([&]() {
+        hipStream_t cs = nullptr;
+        try {
+            FR3D_HIP(hipSetDevice(device));
+            FR3D_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            auto upload = [&](int k) {
+                const int q = k % nset, nt = count_of(k);
+                const size_t o = (size_t)k * win * nv * C;
+                FR3D_HIP(hipMemcpyAsync(dbp[q], batch_proc + o, nv * C * 4 * (size_t)nt, hipMemcpyHostToDevice, cs));
+                FR3D_HIP(hipMemcpyAsync(dbr[q], batch_raw + o, nv * C * 4 * (size_t)nt, hipMemcpyHostToDevice, cs));
+                FR3D_HIP(hipStreamSynchronize(cs));
+                std::lock_guard<std::mutex> lk(mu);
+                uploaded = k + 1;
+                cv.notify_all();
+            };
+            for (int k = 0; k < std::min(nset, nwin); k++) upload(k);
+            for (int k = 0; k < nwin; k++) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return computed > k || abort_all; });
+                    if (abort_all) break;
+                }
+                const int q = k % nset, nt = count_of(k);
+                FR3D_HIP(hipMemcpyAsync(flows_out + (size_t)k * win * nv * 3, dfl[q], nv * 3 * 4 * (size_t)nt,
+                                        hipMemcpyDeviceToHost, cs));
+                FR3D_HIP(hipMemcpyAsync(registered_out + (size_t)k * win * nv * C, dre[q], nv * C * 4 * (size_t)nt,
+                                        hipMemcpyDeviceToHost, cs));
+                FR3D_HIP(hipStreamSynchronize(cs));
+                if (k + nset < nwin) upload(k + nset);
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu);
+            copier_error = std::current_exception();
+            abort_all = true;
+            cv.notify_all();
+        }
+        if (cs) (void)hipStreamDestroy(cs);
+    });
+    std::exception_ptr main_error;
+    try {
+        for (int k = 0; k < nwin; k++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return uploaded > k || abort_all; });
+                if (abort_all) break;
+            }
+            const int q = k % nset;
+            process_batch_dev(p, dbp[q], dbr[q], drp, drr, dwi, dwt, count_of(k), Z, Y, X, C, order, dfl[q], dre[q],
+                              progress, user);  // returns with the engine stream drained
+            std::lock_guard<std::mutex> lk(mu);
+            computed = k + 1;
+            cv.notify_all();
+        }
+    } catch (...) {
+        main_error = std::current_exception();
+        std::lock_guard<std::mutex> lk(mu);
+        abort_all = true;
+        cv.notify_all();
+    }
+    copier.join();
+    if (main_error) std::rethrow_exception(main_error);
+    if (copier_error) std::rethrow_exception(copier_error);
     FR3D_CATCH
 }
 

@@ -146,7 +146,11 @@ class HipExecutor3D:
         wi = None if w_init is None else f32(w_init, (Z, Y, X, 3))
         w32 = None if wt is None else f32(wt, (Z, Y, X, nc))
         flows = np.empty((T, Z, Y, X, 3), np.float32)
-        reg32 = np.empty((T, Z, Y, X, nc), np.float32)
+        # registered[t] = reg_volume stores fp32 into an array of batch.dtype (sequential_3d.py:75,163-170):
+        # a float32 batch receives the device result directly, other dtypes go through one cast
+        registered = np.empty_like(batch)
+        direct = registered.dtype == np.float32 and registered.flags.c_contiguous
+        reg32 = registered if direct else np.empty((T, Z, Y, X, nc), np.float32)
 
         cb_error = []
 
@@ -164,7 +168,6 @@ class HipExecutor3D:
                                           _lib.ptr(reg32), cb, None))
         if cb_error:
             raise cb_error[0]
-        # registered[t] = reg_volume stores fp32 into an array of batch.dtype (sequential_3d.py:75,163-170)
-        registered = np.empty_like(batch)
-        registered[...] = reg32
+        if not direct:
+            registered[...] = reg32
         return registered, flows
