@@ -93,14 +93,16 @@ def cpu_baseline(workload, sample_edge):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=80, help="edge of the CPU-baseline cube")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solver-fp64", type=int, default=0, choices=(0, 1, 2),
                     help="0 fp32 storage+update (default), 1 fp64 update arithmetic, 2 fp64 storage (parity-grade)")
-    ap.add_argument("--batch", type=int, default=4, help="volumes solved in lock step per GPU (shared launches)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="volumes solved in lock step per GPU (shared launches); 0 = 8, or 4 at 512^3 "
+                         "where 8 slabs of solver operands (43 GB each) would not fit in 288 GB")
     ap.add_argument("--condition", type=float, default=15.0,
                     help="seconds of untimed warm-up work before the timed steps (0 = only the W warm-up steps)")
     args = ap.parse_args()
@@ -163,7 +165,7 @@ def main():
                                      batch.ptr + i * nv * 4))
     gflow.free()
 
-    batch_vols = max(1, min(K, args.batch))
+    batch_vols = max(1, min(K, args.batch if args.batch > 0 else (4 if args.workload == "cfg3" else 8)))
     lib.fr3d_set_batch(batch_vols)  # warm-up and timed run use the same lock-step batch / workspace
 
     def run(first, count, prof):

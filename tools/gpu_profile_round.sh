@@ -8,9 +8,10 @@ out=gpurun_out/$tag; mkdir -p $out
 python3 bench.py > $out/bench_cfg2.json 2> $out/bench_cfg2.err || { tail -3 $out/bench_cfg2.err; exit 1; }
 python3 bench.py --workload cfg3 --steps 4 --warmup 1 > $out/bench_cfg3.json 2> $out/bench_cfg3.err || { tail -3 $out/bench_cfg3.err; exit 1; }
 for wl in cfg2 cfg3; do
+  steps=8; [ $wl = cfg3 ] && steps=4   # same steps / lock-step batch as the bench lines above
   # warm-up 0: every k_sor_step dispatch in the stats belongs to the timed region, so rocprof's average
   # duration is directly comparable with the HIP-event figure in the JSON line of the same run
-  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/_kt_$wl -- python3 bench.py --workload $wl --steps 4 --warmup 0 --no-cpu-baseline > $out/rocprof_$wl.log 2>&1 || exit 1
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/_kt_$wl -- python3 bench.py --workload $wl --steps $steps --warmup 0 --no-cpu-baseline > $out/rocprof_$wl.log 2>&1 || exit 1
   grep -o '"avg_launch_us": [0-9.]*\|"launches": [0-9]*' $out/rocprof_$wl.log | tr '\n' ' ' > $out/rocprof_${wl}_hipevents.txt
   cp $(find $out/_kt_$wl -name "*kernel_stats.csv" | head -1) $out/kernel_stats_$wl.csv
   timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/_pf_$wl -- python3 bench.py --workload $wl --steps 1 --warmup 0 --batch 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
