@@ -1,10 +1,14 @@
 // k_median.hip -- K8: exact 5x5x5 median with mirror boundary
 // (scipy.ndimage.median_filter(size=(5,5,5), mode="mirror"), core/optical_flow_3d.py:517-526).
 //
-// Rank 62 of 125 by a selection network: the window is held in 128 VGPRs (3 slots padded with
-// +inf) and pushed through Batcher's odd-even merge sort with every index static, of which the
-// compiler keeps only the min/max operations that can reach output 62.  Compute-bound, exact for
-// any input (no histogram / approximation), no scratch.
+// Rank 62 of 125 by selection networks built from Batcher's odd-even merge sort with every index
+// static, of which the compiler keeps only the min/max operations that can reach the wanted outputs.
+// k_median5_x2 (default) computes two neighbouring outputs per thread and shares the sort of the 100
+// window elements they have in common; k_median5 is the one-output-per-thread form (128 VGPR window,
+// 1122 min/max pairs) kept for A/B runs (FR3D_MEDIAN_X1).  Compute-bound, exact for any input (no
+// histogram / approximation).
+#include <cstdlib>
+
 #include "fr3d_internal.h"
 
 namespace fr3d {
@@ -83,10 +87,105 @@ k_median5(const float *__restrict__ in, int Z, int Y, int X, float *__restrict__
     out[t] = a[62];
 }
 
+
+// ---- two outputs per thread -------------------------------------------------------------------
+// The windows of (x0, x0+1) share the four x-columns x0-1..x0+2 = 100 of their 125 elements.  An
+// element of that shared set S with S-rank r has window rank r..r+25, so only S[37..62] can be the
+// rank-62 element of either window: the thread sorts S once (network pruned to those 26 outputs),
+// then per output sorts the private 5x5 slab P (x0-2 resp. x0+3) and takes rank 25 of S[37..62] u P
+// as min_i max(S[36+i], P[25-i]), i = 1..26 (the k-th smallest of two sorted lists as a min of
+// maxes; P[-1] = -inf).  631 min/max pairs per output instead of 1122
+// (tools/numerics/median_network.py), no padding values anywhere: comparators that would touch a
+// slot >= NREAL are dropped statically (+inf pads in the top slots never move in a sorting network).
+template <int NARR, int NREAL, int LO, int N, int R>
+struct OEMergeB {
+    static __device__ __forceinline__ void run(float (&a)[NARR])
+    {
+        constexpr int M = R * 2;
+        if constexpr (M < N) {
+            OEMergeB<NARR, NREAL, LO, N, M>::run(a);
+            OEMergeB<NARR, NREAL, LO + R, N, M>::run(a);
+#pragma unroll
+            for (int i = LO + R; i + R < LO + N; i += M)
+                if (i + R < NREAL) cex(a[i], a[i + R]);
+        } else {
+            if constexpr (LO + R < NREAL) cex(a[LO], a[LO + R]);
+        }
+    }
+};
+template <int NARR, int NREAL, int LO, int N>
+struct OESortB {
+    static __device__ __forceinline__ void run(float (&a)[NARR])
+    {
+        if constexpr (N > 1 && LO < NREAL) {
+            OESortB<NARR, NREAL, LO, N / 2>::run(a);
+            OESortB<NARR, NREAL, LO + N / 2, N / 2>::run(a);
+            OEMergeB<NARR, NREAL, LO, N, 1>::run(a);
+        }
+    }
+};
+
+__device__ __forceinline__ float select_shared_private(const float (&s)[128], const float (&p)[32])
+{
+    // rank 25 of s[37..62] (26 sorted) u p[0..24] (25 sorted)
+    float best = s[62];  // i = 26: max(S[62], -inf)
+#pragma unroll
+    for (int i = 1; i <= 25; i++) best = fminf(best, fmaxf(s[36 + i], p[25 - i]));
+    return best;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+k_median5_x2(const float *__restrict__ in, int Z, int Y, int X, float *__restrict__ out)
+{
+    const int XP = (X + 1) >> 1;  // output pairs per row
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)Z * Y * XP;
+    if (t >= total) return;
+    const int xp = (int)(t % XP);
+    long long r = t / XP;
+    const int y = (int)(r % Y);
+    const int z = (int)(r / Y);
+    const int x0 = 2 * xp;
+    long long zo[5], yo[5];
+    int xo[6];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        zo[q] = (long long)mirror(z + q - 2, Z) * Y * X;
+        yo[q] = (long long)mirror(y + q - 2, Y) * X;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) xo[q] = mirror(x0 + q - 2, X);  // columns x0-2 .. x0+3
+    float s[128];
+#pragma unroll
+    for (int n = 0; n < 100; n++) s[n] = in[zo[n / 20] + yo[(n / 4) % 5] + xo[1 + n % 4]];
+    OESortB<128, 100, 0, 128>::run(s);
+    const size_t o = ((size_t)z * Y + y) * X + x0;
+    {
+        float p[32];
+#pragma unroll
+        for (int n = 0; n < 25; n++) p[n] = in[zo[n / 5] + yo[n % 5] + xo[0]];
+        OESortB<32, 25, 0, 32>::run(p);
+        out[o] = select_shared_private(s, p);
+    }
+    if (x0 + 1 < X) {
+        float p[32];
+#pragma unroll
+        for (int n = 0; n < 25; n++) p[n] = in[zo[n / 5] + yo[n % 5] + xo[5]];
+        OESortB<32, 25, 0, 32>::run(p);
+        out[o + 1] = select_shared_private(s, p);
+    }
+}
+
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out)
 {
-    long long total = (long long)Z * Y * X;
-    hipLaunchKernelGGL(k_median5, dim3(cdiv(total, 256)), dim3(256), 0, st, in, Z, Y, X, out);
+    static const bool one_per_thread = getenv("FR3D_MEDIAN_X1") != nullptr;  // A/B aid
+    if (one_per_thread) {
+        long long total = (long long)Z * Y * X;
+        hipLaunchKernelGGL(k_median5, dim3(cdiv(total, 256)), dim3(256), 0, st, in, Z, Y, X, out);
+        return;
+    }
+    long long total = (long long)Z * Y * ((X + 1) / 2);
+    hipLaunchKernelGGL(k_median5_x2, dim3(cdiv(total, 256)), dim3(256), 0, st, in, Z, Y, X, out);
 }
 
 }  // namespace fr3d

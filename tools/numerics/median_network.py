@@ -85,3 +85,26 @@ if __name__ == "__main__":
     real = [(s % 32) < 25 and s < 160 for s in range(256)]
     print("merge 5x25 -> rank 62   :", count(c, real, [62]))
     # alternative stage 3 with lists trimmed (see notes): only the ranks that can still be the median
+
+
+def two_outputs_per_thread():
+    """Thread computes the medians at x and x+1: the 100 shared window elements are sorted once
+    (only ranks 37..62 of them can hold either median), each output then sorts its private slab of
+    25 and selects rank 62-37 = 25 of (26 shared candidates + 25 private)."""
+    c = []
+    oesort(0, 128, c)
+    shared = count(c, [s < 100 for s in range(128)], range(37, 63))
+    c = []
+    oesort(0, 32, c)
+    slab = count(c, [s < 25 for s in range(32)], range(25))
+    # merge 26 (padded to 32) with 25 (padded to 32) -> rank 25
+    c = []
+    oemerge(0, 64, 1, c)
+    real = [(s < 26) or (32 <= s < 57) for s in range(64)]
+    sel = count(c, real, [25])
+    print("2 outputs/thread: shared sort100->ranks 37..62", shared, " slab sort25", slab, " final select", sel)
+    print("   per output: %.0f min/max pairs" % (shared[0] / 2 + slab[0] + sel[0]))
+
+
+if __name__ == "__main__":
+    two_outputs_per_thread()
