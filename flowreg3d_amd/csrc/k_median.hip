@@ -3,9 +3,10 @@
 //
 // Rank 62 of 125 by selection networks built from Batcher's odd-even merge sort with every index
 // static, of which the compiler keeps only the min/max operations that can reach the wanted outputs.
-// k_median5_x2 (default) computes two neighbouring outputs per thread and shares the sort of the 100
-// window elements they have in common; k_median5 is the one-output-per-thread form (128 VGPR window,
-// 1122 min/max pairs) kept for A/B runs (FR3D_MEDIAN_X1).  Compute-bound, exact for any input (no
+// k_median5_lds (default) sorts every 5x5 slab once per workgroup and builds two neighbouring outputs
+// per thread from six sorted slabs (345 min/max pairs per output); k_median5_x2 is the same pairing
+// without the LDS exchange (631 pairs) and k_median5 the one-output-per-thread form (1122 pairs),
+// both kept for A/B runs (FR3D_MEDIAN=2 / 1).  Compute-bound, exact for any input (no
 // histogram / approximation).
 #include <cstdlib>
 
@@ -176,16 +177,150 @@ k_median5_x2(const float *__restrict__ in, int Z, int Y, int X, float *__restric
     }
 }
 
+
+// ---- slabs sorted once, exchanged through LDS ---------------------------------------------------
+// The 5x5 (z,y) slab at one x belongs to five windows.  A workgroup of 4 rows x 64 output pairs sorts
+// every slab of its 133 columns once (each thread its own two columns, five threads per row a halo
+// column too), publishes them in LDS as order-preserving integer keys, and each thread then builds
+// its pair of medians from six sorted slabs: the four shared ones are MERGED (odd-even merge levels
+// only, 360 min/max pairs for the 26 candidate ranks instead of 932 for sorting them from scratch),
+// the two private ones are used as they are.  345 pairs per output.  Lists of 25 sit in 32-slot
+// blocks padded with INT_MAX; integer min/max against that constant folds away at compile time
+// (float min/max against +inf cannot, because of NaN semantics), which is why keys are integers.
+// (A fifth wave for the halo columns was tried: 320-thread workgroups fit only twice per CU next to
+// 53 KB of LDS each, 5.0 ms instead of 4.2 ms per 256^3 volume.)
+__device__ __forceinline__ int f2key(float f)
+{
+    const int b = __float_as_int(f);
+    return b ^ ((b >> 31) & 0x7fffffff);  // signed-integer order == float order; its own inverse
+}
+__device__ __forceinline__ float key2f(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+__device__ __forceinline__ void cexi(int &a, int &b)
+{
+    const int lo = min(a, b), hi = max(a, b);
+    a = lo;
+    b = hi;
+}
+template <int NARR, int LO, int N, int R>
+struct OEMergeI {
+    static __device__ __forceinline__ void run(int (&a)[NARR])
+    {
+        constexpr int M = R * 2;
+        if constexpr (M < N) {
+            OEMergeI<NARR, LO, N, M>::run(a);
+            OEMergeI<NARR, LO + R, N, M>::run(a);
+#pragma unroll
+            for (int i = LO + R; i + R < LO + N; i += M) cexi(a[i], a[i + R]);
+        } else {
+            cexi(a[LO], a[LO + R]);
+        }
+    }
+};
+template <int NARR, int LO, int N>
+struct OESortI {
+    static __device__ __forceinline__ void run(int (&a)[NARR])
+    {
+        if constexpr (N > 1) {
+            OESortI<NARR, LO, N / 2>::run(a);
+            OESortI<NARR, LO + N / 2, N / 2>::run(a);
+            OEMergeI<NARR, LO, N, 1>::run(a);
+        }
+    }
+};
+
+#define MB_Y 4
+#define MB_XP 64                    // output pairs per block row -> 128 outputs, 133 slab columns
+#define MB_NE (MB_XP + 3)           // even columns c = 0,2,..,132
+#define MB_NO (MB_XP + 2)           // odd columns  c = 1,3,..,131
+#define KEY_PAD 0x7fffffff
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+k_median5_lds(const float *__restrict__ in, int Z, int Y, int X, float *__restrict__ out)
+{
+    // column c of the block is x = X0 - 2 + c; even and odd columns are stored apart so that the
+    // lanes of a wave (consecutive pairs) read consecutive words
+    __shared__ int sE[25][MB_Y][MB_NE];
+    __shared__ int sO[25][MB_Y][MB_NO];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int z = blockIdx.z;
+    const int y = blockIdx.y * MB_Y + ty;
+    const int X0 = blockIdx.x * (2 * MB_XP);
+    const bool row_ok = y < Y;
+    long long zo[5], yo[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        zo[q] = (long long)mirror(z + q - 2, Z) * Y * X;
+        yo[q] = (long long)mirror(row_ok ? y + q - 2 : 0, Y) * X;
+    }
+    auto sort_column = [&](int c) {
+        const int xm = mirror(X0 - 2 + c, X);
+        int k[32];
+#pragma unroll
+        for (int n = 0; n < 25; n++) k[n] = f2key(in[zo[n / 5] + yo[n % 5] + xm]);
+#pragma unroll
+        for (int n = 25; n < 32; n++) k[n] = KEY_PAD;
+        OESortI<32, 0, 32>::run(k);
+        if (c & 1) {
+#pragma unroll
+            for (int n = 0; n < 25; n++) sO[n][ty][c >> 1] = k[n];
+        } else {
+#pragma unroll
+            for (int n = 0; n < 25; n++) sE[n][ty][c >> 1] = k[n];
+        }
+    };
+    if (row_ok) {
+        sort_column(2 * tx + 2);
+        sort_column(2 * tx + 3);
+        if (tx < 5) sort_column(tx < 2 ? tx : 2 * MB_XP + tx);  // halo columns 0,1 and 130,131,132
+    }
+    __syncthreads();
+    const int x0 = X0 + 2 * tx;
+    if (!row_ok || x0 >= X) return;
+    // columns x0-2 .. x0+3 are c = 2tx .. 2tx+5: even ones at sE[..][tx + 0/1/2], odd at sO[..][tx + 0/1/2]
+    int s[128];
+#pragma unroll
+    for (int n = 0; n < 25; n++) {
+        s[n] = sO[n][ty][tx];            // x0-1
+        s[32 + n] = sE[n][ty][tx + 1];   // x0
+        s[64 + n] = sO[n][ty][tx + 1];   // x0+1
+        s[96 + n] = sE[n][ty][tx + 2];   // x0+2
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int n = 25; n < 32; n++) s[32 * b + n] = KEY_PAD;
+    OEMergeI<128, 0, 64, 1>::run(s);
+    OEMergeI<128, 64, 64, 1>::run(s);
+    OEMergeI<128, 0, 128, 1>::run(s);
+    const size_t o = ((size_t)z * Y + y) * X + x0;
+    {
+        int best = s[62];
+#pragma unroll
+        for (int i = 1; i <= 25; i++) best = min(best, max(s[36 + i], sE[25 - i][ty][tx]));  // private x0-2
+        out[o] = key2f(best);
+    }
+    if (x0 + 1 < X) {
+        int best = s[62];
+#pragma unroll
+        for (int i = 1; i <= 25; i++) best = min(best, max(s[36 + i], sO[25 - i][ty][tx + 2]));  // private x0+3
+        out[o + 1] = key2f(best);
+    }
+}
+
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out)
 {
-    static const bool one_per_thread = getenv("FR3D_MEDIAN_X1") != nullptr;  // A/B aid
-    if (one_per_thread) {
+    static const char *env = getenv("FR3D_MEDIAN");  // A/B aid: 1 = one output per thread, 2 = pairs without LDS
+    const int mode = env ? atoi(env) : 0;
+    if (mode == 1) {
         long long total = (long long)Z * Y * X;
         hipLaunchKernelGGL(k_median5, dim3(cdiv(total, 256)), dim3(256), 0, st, in, Z, Y, X, out);
-        return;
+    } else if (mode == 2 || Z > 65535 || cdiv(Y, MB_Y) > 65535) {
+        long long total = (long long)Z * Y * ((X + 1) / 2);
+        hipLaunchKernelGGL(k_median5_x2, dim3(cdiv(total, 256)), dim3(256), 0, st, in, Z, Y, X, out);
+    } else {
+        dim3 grid(cdiv(X, 2 * MB_XP), cdiv(Y, MB_Y), Z);
+        hipLaunchKernelGGL(k_median5_lds, grid, dim3(256), 0, st, in, Z, Y, X, out);
     }
-    long long total = (long long)Z * Y * ((X + 1) / 2);
-    hipLaunchKernelGGL(k_median5_x2, dim3(cdiv(total, 256)), dim3(256), 0, st, in, Z, Y, X, out);
 }
 
 }  // namespace fr3d

@@ -108,3 +108,17 @@ def two_outputs_per_thread():
 
 if __name__ == "__main__":
     two_outputs_per_thread()
+
+
+def merged_slabs():
+    """Shared set of an output pair as a merge of four pre-sorted 25-slabs (exchanged through LDS)."""
+    c = []
+    for blk in range(0, 128, 64):
+        oemerge(blk, 64, 1, c)
+    oemerge(0, 128, 1, c)
+    real = [(s % 32) < 25 for s in range(128)]
+    print("merge 4 sorted 25-slabs -> ranks 37..62:", count(c, real, range(37, 63)))
+
+
+if __name__ == "__main__":
+    merged_slabs()
