@@ -176,7 +176,7 @@ def ptr(a):
 
 
 def make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth, a_data, n_channels,
-                solver_fp64=False) -> Params:
+                solver_fp64=None) -> Params:
     p = Params()
     al = np.asarray(alpha, dtype=np.float64).reshape(-1)
     if al.size == 1:
@@ -199,7 +199,8 @@ def make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth,
         raise ValueError(f"at most {MAX_CHANNELS} channels")
     for c in range(n_channels):
         p.a_data[c] = float(ad[c])
-    p.solver_fp64 = int(solver_fp64) if solver_fp64 in (0, 1, 2, True, False) else 1
+    # None = FR3D_SOLVER_AUTO: fp32 solver storage for one channel, fp64 for several
+    p.solver_fp64 = -1 if solver_fp64 is None else (int(solver_fp64) if solver_fp64 in (0, 1, 2, True, False) else 1)
     return p
 
 

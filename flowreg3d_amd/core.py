@@ -80,12 +80,13 @@ def _f32c(a):
 
 def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=20, min_level=0,
                      levels=50, eta=0.8, a_smooth=0.5, a_data=0.45, const_assumption="gc",
-                     uvw=None, weight=None, solver_fp64=False):
+                     uvw=None, weight=None, solver_fp64=None):
     """core/optical_flow_3d.py:319-542 -> (Z,Y,X,3) float64 with components [dx,dy,dz].
 
     fixed/moving are used by the reference only through the fp32 resampler
     (util/resize_util_3D.py:116), and uvw/weight likewise, so they cross the ABI as float32.
-    ``solver_fp64`` is an extension: fp64 update arithmetic in the SOR kernel (storage stays fp32).
+    ``solver_fp64`` is an extension (fr3d_params.solver_fp64): None = automatic (fp32 solver storage
+    for one channel, fp64 for several), 0 / 1 / 2 force fp32 / fp64 arithmetic / fp64 storage.
     """
     fixed = np.asarray(fixed)
     moving = np.asarray(moving)

@@ -579,10 +579,17 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
     }
 }
 
-static void get_displacement_core(Engine &e, const fr3d_params &p, const std::vector<Level> &lv, int min_level,
+// FR3D_SOLVER_AUTO: single-channel problems are well conditioned in fp32 (EPE vs the CPU path 1e-5);
+// with several channels the reference iteration itself amplifies rounding and
+// only fp64 solver storage stays below the 1e-4 bound
+static int solver_mode(const fr3d_params &p, int C) { return p.solver_fp64 < 0 ? (C >= 2 ? 2 : 0) : p.solver_fp64; }
+
+static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std::vector<Level> &lv, int min_level,
                                   const RefPyramid &rp, int nb, const float *const *moving, int Z, int Y, int X,
                                   int C, const float *uvw_init, float *const *flow_out, int reserve_nb = 1)
 {
+    fr3d_params p = p_in;
+    p.solver_fp64 = solver_mode(p_in, C);
     if (p.solver_fp64 == 2)
         get_displacement_core_t<double>(e, p, lv, min_level, rp, nb, moving, Z, Y, X, C, uvw_init, flow_out, reserve_nb);
     else
@@ -691,7 +698,7 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     // the fixed-reference pyramid and the weight pyramid are time-invariant: build once
     build_ref_pyramid(e, lv, ref_proc, weight, Z, Y, X, C, rp, "pb_");
     const size_t nv = (size_t)Z * Y * X;
-    g_fp64_storage = p->solver_fp64 == 2;
+    g_fp64_storage = solver_mode(*p, C) == 2;
     const int B = T > 0 ? pick_batch(T, lv, C) : 1;
     // T volumes in ceil(T/B) lock-step batches of (nearly) equal size: 10 volumes at B = 4 run as
     // 4+3+3, not 4+4+2 (the shared launches amortise best over evenly filled batches)

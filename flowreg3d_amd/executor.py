@@ -130,7 +130,8 @@ class HipExecutor3D:
         a_smooth = float(fp.get("a_smooth", 0.5))
         params = _lib.make_params(alpha, fp.get("update_lag", 10), fp.get("iterations", 20),
                                   fp.get("min_level", 0), fp.get("levels", 50), fp.get("eta", 0.8), a_smooth,
-                                  fp.get("a_data", 0.45), nc, int(fp.get("solver_fp64", 0)))
+                                  fp.get("a_data", 0.45), nc,
+                                  None if fp.get("solver_fp64") is None else int(fp["solver_fp64"]))
         wt = expand_weight(fp.get("weight", None), Z, Y, X, nc)
 
         def f32(a, shape):

@@ -48,7 +48,7 @@ class Options:
     channel_normalization: str = "together"
     interpolation_method: str = "cubic"
     update_initialization_w: bool = True
-    solver_fp64: int = 0  # extension: 2 selects fp64 solver storage
+    solver_fp64: Optional[int] = None  # extension: None = fp32 solver storage for one channel, fp64 for several
 
     @property
     def effective_min_level(self) -> int:
@@ -133,7 +133,7 @@ class BatchMotionCorrectorHip:
                 "min_level": int(getattr(o, "effective_min_level", getattr(o, "min_level", 0))),
                 "eta": float(_opt(o, "eta", 0.8)), "update_lag": int(_opt(o, "update_lag", 5)),
                 "iterations": int(_opt(o, "iterations", 100)), "a_smooth": float(_opt(o, "a_smooth", 1.0)),
-                "a_data": _opt(o, "a_data", 0.45), "solver_fp64": int(_opt(o, "solver_fp64", 0))}
+                "a_data": _opt(o, "a_data", 0.45), "solver_fp64": _opt(o, "solver_fp64", None)}
 
     def _preprocess(self, frames, normalization_ref=None):
         return preprocess_frames(frames, normalization_ref=normalization_ref, sigma=np.asarray(_opt(self.options, "sigma", None)),

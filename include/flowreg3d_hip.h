@@ -47,13 +47,16 @@ typedef struct fr3d_params {
     double a_smooth;                   /* 1.0: constant diffusion (fast path); otherwise psi_smooth is
                                           re-evaluated every iteration (k_sor_smooth.hip) */
     double a_data[FR3D_MAX_CHANNELS];  /* per channel */
-    int solver_fp64;                   /* 0: fp32 storage + fp32 update arithmetic (default);
+    int solver_fp64;                   /* 0: fp32 storage + fp32 update arithmetic;
                                           1: fp32 storage, fp64 update arithmetic;
                                           2: fp64 storage and arithmetic in the solver (2x the
                                              bytes; for configurations where the reference's own
-                                             iteration is ill-conditioned) */
+                                             iteration is ill-conditioned);
+                                          FR3D_SOLVER_AUTO (-1): 0 for one channel, 2 for several
+                                             (what the Python mirror passes by default) */
     int reserved[7];
 } fr3d_params;
+#define FR3D_SOLVER_AUTO (-1)
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 int fr3d_init(int device);              /* hipSetDevice + stream + workspace; idempotent */

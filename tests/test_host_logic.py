@@ -52,7 +52,9 @@ def test_make_params():
     from flowreg3d_amd import _lib
     p = _lib.make_params((0.25, 0.5, 1.0), 5, 100, 0, 4, 0.8, 1.0, [0.45, 0.6], 2)
     assert list(p.alpha) == [0.25, 0.5, 1.0] and p.iterations == 100 and p.update_lag == 5
-    assert p.a_data[0] == 0.45 and p.a_data[1] == 0.6 and p.solver_fp64 == 0
+    assert p.a_data[0] == 0.45 and p.a_data[1] == 0.6 and p.solver_fp64 == -1  # FR3D_SOLVER_AUTO
+    assert _lib.make_params(1, 10, 20, 0, 50, 0.8, 1.0, 0.45, 1, solver_fp64=0).solver_fp64 == 0
+    assert _lib.make_params(1, 10, 20, 0, 50, 0.8, 1.0, 0.45, 1, solver_fp64=2).solver_fp64 == 2
     p = _lib.make_params(2, 10, 20, 0, 50, 0.8, 1.0, 0.45, 3, solver_fp64=True)
     assert list(p.alpha) == [2.0, 2.0, 2.0] and p.a_data[2] == 0.45 and p.solver_fp64 == 1
     with pytest.raises(ValueError):
