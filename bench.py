@@ -223,6 +223,10 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         achieved = sor["algo_bytes"] / (sor["ms"] * 1e-3) / 1e9 if sor["ms"] > 0 else 0.0
+        # what a plain y += x stream reaches on this device right now (1 GiB arrays, after the timed
+        # steps): the practical ceiling behind the nominal 8 TB/s
+        stream = C.c_double(0.0)
+        _lib.check(lib.fr3d_stream_probe(1 << 28, 20, C.byref(stream)))
         out = {
             "metric": "volumes/sec (3D flow solve + warp)",
             "value": (K * world) / elapsed,
@@ -247,7 +251,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algo_bytes_per_launch": sor["algo_bytes"] / max(sor["launches"], 1),
                          "avg_launch_us": 1e3 * sor["ms"] / max(sor["launches"], 1),
-                         "launches": sor["launches"]},
+                         "launches": sor["launches"],
+                         "stream_measured": round(stream.value, 1),
+                         "frac_of_stream_measured": round(achieved / stream.value, 4) if stream.value > 0 else None},
             "kernel_ms_per_step": {k: round(v["ms"] / K, 3) for k, v in stats.items()},
             # the other stages of the path against the same HBM roofline, algorithmic bytes as in
             # DESIGN.md section 5 (warp: 24 B/voxel; the median is compute-bound and listed for completeness)

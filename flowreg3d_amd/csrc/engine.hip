@@ -1416,6 +1416,29 @@ int fr3d_prof_reset(void)
     std::memset(g_eng.acc, 0, sizeof(g_eng.acc));
     FR3D_CATCH
 }
+int fr3d_stream_probe(size_t n_floats, int reps, double *gbytes_per_s)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(n_floats > 0 && reps > 0 && gbytes_per_s, "bad stream_probe arguments");
+    Engine &e = g_eng;
+    Staged s;
+    float *x = (float *)s.alloc(n_floats * 4), *y = (float *)s.alloc(n_floats * 4);
+    FR3D_HIP(hipMemsetAsync(x, 0, n_floats * 4, e.st));
+    FR3D_HIP(hipMemsetAsync(y, 0, n_floats * 4, e.st));
+    launch_axpy(e.st, y, x, (long long)n_floats);  // first touch outside the timed part
+    hipEvent_t a = e.get_event(), b = e.get_event();
+    FR3D_HIP(hipEventRecord(a, e.st));
+    for (int r = 0; r < reps; r++) launch_axpy(e.st, y, x, (long long)n_floats);
+    FR3D_HIP(hipEventRecord(b, e.st));
+    FR3D_HIP(hipEventSynchronize(b));
+    float ms = 0.0f;
+    FR3D_HIP(hipEventElapsedTime(&ms, a, b));
+    e.ev_pool.push_back(a);
+    e.ev_pool.push_back(b);
+    *gbytes_per_s = 12.0 * (double)n_floats * reps / ((double)ms * 1e-3) / 1e9;
+    FR3D_CATCH
+}
 int fr3d_prof_get(fr3d_kernel_stat *out)
 {
     FR3D_TRY

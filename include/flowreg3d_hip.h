@@ -193,6 +193,10 @@ typedef struct fr3d_kernel_stat {
 int fr3d_prof_enable(int on);   /* off by default: brackets cost two events per stage */
 int fr3d_prof_reset(void);
 int fr3d_prof_get(fr3d_kernel_stat *out /* FR3D_K_COUNT entries */);
+/* Streaming rate this device sustains right now: `reps` launches of y += x over two arrays of
+ * n_floats (12 B per element: two reads, one write), HIP-event timed on the engine stream.  The
+ * practical ceiling next to the nominal 8 TB/s when reading roofline fractions. */
+int fr3d_stream_probe(size_t n_floats, int reps, double *gbytes_per_s);
 
 #ifdef __cplusplus
 }

@@ -110,3 +110,13 @@ def test_c_abi_rejects_bad_arguments(hip):
     assert lib.fr3d_get_displacement(C.byref(p), _lib.ptr(z), _lib.ptr(z), 4, 4, 4, 1, None, None, _lib.ptr(out)) != 0
     assert lib.fr3d_warp(_lib.ptr(z), 0, _lib.ptr(out), 0, _lib.ptr(z), 4, 4, 4, 1, 2, _lib.ptr(z)) != 0
     assert _lib.last_error().startswith("Unsupported interpolation")
+
+
+def test_stream_probe_reports_a_plausible_rate(hip):
+    import ctypes as C
+    from flowreg3d_amd import _lib
+    lib = _lib.init()
+    rate = C.c_double(0.0)
+    _lib.check(lib.fr3d_stream_probe(1 << 26, 5, C.byref(rate)))
+    assert 500.0 < rate.value < 8000.0, rate.value  # GB/s: below the nominal HBM peak, far above PCIe
+    assert lib.fr3d_stream_probe(0, 5, C.byref(rate)) != 0
