@@ -94,7 +94,16 @@ k_resize_mid(const float *__restrict__ src, int n, long long inner, int out_len,
     const int *ii = idx + (size_t)i * P;
     const float *ww = wt + (size_t)i * P;
     float a = 0.0f;
-    for (int p = 0; p < P; p++) a += base[(size_t)ii[p] * inner] * ww[p];  // tap order as the reference
+    // taps in groups of 8: the gathers of a group are independent and leave together, the sum keeps
+    // the reference's tap order (a one-tap-per-trip loop waits for every load in turn)
+    for (int p0 = 0; p0 < P; p0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = p0 + q < P ? base[(size_t)ii[p0 + q] * inner] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (p0 + q < P) a += v[q] * ww[p0 + q];
+    }
     dst[((size_t)o * out_len + i) * inner + x] = a;
 }
 

@@ -226,11 +226,17 @@ k_skew_tiled(const TS *__restrict__ src, long long src_stride, TD *__restrict__ 
     src += (size_t)blockIdx.z * src_stride;
     dst += (size_t)blockIdx.z * dst_stride;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // global loads are fetched into registers in groups of 16 before any of them is written to LDS:
+    // a load-then-store loop makes every trip wait for its own load
     if (to_skew) {
-        for (int row = wave; row < SKT; row += 4) {
-            const int y = y0 + row, x = x0 + lane;
-            if (y < Y && x < X) tile[row][lane] = (TD)src[((size_t)z * Y + y) * X + x];
+        TS v[SKT / 4];
+#pragma unroll
+        for (int q = 0; q < SKT / 4; q++) {
+            const int y = y0 + wave + 4 * q, x = x0 + lane;
+            v[q] = (y < Y && x < X) ? src[((size_t)z * Y + y) * X + x] : (TS)0;
         }
+#pragma unroll
+        for (int q = 0; q < SKT / 4; q++) tile[wave + 4 * q][lane] = (TD)v[q];
         __syncthreads();
         for (int d = wave; d < 2 * SKT - 1; d += 4) {
             const int ly = lane, lx = d - lane;
@@ -238,10 +244,23 @@ k_skew_tiled(const TS *__restrict__ src, long long src_stride, TD *__restrict__ 
             if (lx >= 0 && lx < SKT && y < Y && x < X) dst[(size_t)sk_index(X, Yp, plane, z, y, x)] = tile[ly][lx];
         }
     } else {
-        for (int d = wave; d < 2 * SKT - 1; d += 4) {
-            const int ly = lane, lx = d - lane;
-            const int y = y0 + ly, x = x0 + lx;
-            if (lx >= 0 && lx < SKT && y < Y && x < X) tile[ly][lx] = (TD)src[(size_t)sk_index(X, Yp, plane, z, y, x)];
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            TS v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int d = wave + 4 * (16 * g + q);
+                const int ly = lane, lx = d - lane;
+                const int y = y0 + ly, x = x0 + lx;
+                const bool ok = d < 2 * SKT - 1 && lx >= 0 && lx < SKT && y < Y && x < X;
+                v[q] = ok ? src[(size_t)sk_index(X, Yp, plane, z, y, x)] : (TS)0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int d = wave + 4 * (16 * g + q);
+                const int lx = d - lane;
+                if (d < 2 * SKT - 1 && lx >= 0 && lx < SKT) tile[lane][lx] = (TD)v[q];
+            }
         }
         __syncthreads();
         for (int row = wave; row < SKT; row += 4) {

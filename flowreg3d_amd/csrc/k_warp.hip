@@ -138,12 +138,18 @@ k_prefilter_x_tiled(double *c, long long nrows, int n)
     const int lr = lane >> 5, lc = lane & 31;  // 2 rows x 32 columns per wave-load
 
     auto load_tile = [&](int t) {
+        // 16 row segments in flight per group (a load-then-store loop waits for each load in turn)
         int col = t * PF_TW + lc;
-        for (int r = 0; r < 64; r += 2) {
-            long long row = row0 + r + lr;
-            double v = 0.0;
-            if (row < nrows && col < n) v = c[row * n + col];
-            tile[r + lr][lc] = v;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                long long row = row0 + 2 * (16 * g + q) + lr;
+                v[q] = (row < nrows && col < n) ? c[row * n + col] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) tile[2 * (16 * g + q) + lr][lc] = v[q];
         }
     };
     auto store_tile = [&](int t) {
@@ -265,6 +271,9 @@ __device__ __forceinline__ void bspline3_weights(double cc, double *w, int *star
     w[3] = w3;
 }
 
+#ifndef WARP_ZB
+#define WARP_ZB 1  // z-taps whose 16 coefficients are in flight together
+#endif
 template <typename TF, typename TR>
 __global__ void __launch_bounds__(256)
 k_warp_cubic(const double *__restrict__ coef, int npad, const TF *__restrict__ pu,
@@ -298,24 +307,39 @@ k_warp_cubic(const double *__restrict__ coef, int npad, const TF *__restrict__ p
     bspline3_weights((double)cz + npad, wz, &sz);
     bspline3_weights((double)cy + npad, wy, &sy);
     bspline3_weights((double)cx + npad, wx, &sx);
+    // The taps are summed in SciPy's order (z, y, x innermost; coefficient * wz * wy * wx), but the 16
+    // coefficients of a z-tap are fetched together first: written as load-multiply-add per tap the
+    // compiler emitted 64 dependent load/wait pairs per voxel.
+    int xi[4], yi[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        xi[e] = clampi(sx + e, PX);
+        yi[e] = clampi(sy + e, PY);
+    }
     double acc = 0.0;
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        int zi = clampi(sz + a, PZ);
+    for (int a0 = 0; a0 < 4; a0 += WARP_ZB) {
+        double c[WARP_ZB][16];
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            int yi = clampi(sy + b, PY);
-            const double *row = coef + ((size_t)zi * PY + yi) * PX;
+        for (int a = 0; a < WARP_ZB; a++) {
+            const double *slab = coef + (size_t)clampi(sz + a0 + a, PZ) * PY * PX;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                int xi = clampi(sx + e, PX);
-                double cf = row[xi];
-                cf *= wz[a];
-                cf *= wy[b];
-                cf *= wx[e];
-                acc += cf;
-            }
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) c[a][4 * b + e] = slab[(size_t)yi[b] * PX + xi[e]];
         }
+#pragma unroll
+        for (int a = 0; a < WARP_ZB; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    double cf = c[a][4 * b + e];
+                    cf *= wz[a0 + a];
+                    cf *= wy[b];
+                    cf *= wx[e];
+                    acc += cf;
+                }
     }
     out[(size_t)t * ocs + oco] = (float)acc;
 }
