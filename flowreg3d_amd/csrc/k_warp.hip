@@ -62,9 +62,10 @@ __device__ __forceinline__ void spline_line(double *c, int n, long long stride, 
         double xi[PF_CH], xr[PF_CH];
 #pragma unroll
         for (int q = 0; q < PF_CH; q++) {
-            const int i = i0 + q;
-            xi[q] = i < lim ? c[(long long)i * stride] : 0.0;
-            xr[q] = (i < lim && i != n - 1) ? c[(long long)(n - 1 - i) * stride] : 0.0;
+            // clamped index, unconditional load: a guarded load becomes branch + load + wait per sample
+            const int i = i0 + q < lim ? i0 + q : lim - 1;
+            xi[q] = c[(long long)i * stride];
+            xr[q] = c[(long long)(n - 1 - i) * stride];
         }
 #pragma unroll
         for (int q = 0; q < PF_CH; q++) {
@@ -86,7 +87,7 @@ __device__ __forceinline__ void spline_line(double *c, int n, long long stride, 
     for (int i0 = 1; i0 < n; i0 += PF_CH) {
         double v[PF_CH];
 #pragma unroll
-        for (int q = 0; q < PF_CH; q++) v[q] = i0 + q < n ? c[(long long)(i0 + q) * stride] : 0.0;
+        for (int q = 0; q < PF_CH; q++) v[q] = c[(long long)(i0 + q < n ? i0 + q : n - 1) * stride];
 #pragma unroll
         for (int q = 0; q < PF_CH; q++)
             if (i0 + q < n) {
@@ -101,7 +102,7 @@ __device__ __forceinline__ void spline_line(double *c, int n, long long stride, 
     for (int i0 = n - 2; i0 >= 0; i0 -= PF_CH) {
         double v[PF_CH];
 #pragma unroll
-        for (int q = 0; q < PF_CH; q++) v[q] = i0 - q >= 0 ? c[(long long)(i0 - q) * stride] : 0.0;
+        for (int q = 0; q < PF_CH; q++) v[q] = c[(long long)(i0 - q >= 0 ? i0 - q : 0) * stride];
 #pragma unroll
         for (int q = 0; q < PF_CH; q++)
             if (i0 - q >= 0) {
@@ -146,7 +147,8 @@ k_prefilter_x_tiled(double *c, long long nrows, int n)
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 long long row = row0 + 2 * (16 * g + q) + lr;
-                v[q] = (row < nrows && col < n) ? c[row * n + col] : 0.0;
+                if (row > nrows - 1) row = nrows - 1;  // clamped, unconditional loads
+                v[q] = c[row * n + (col < n ? col : n - 1)];
             }
 #pragma unroll
             for (int q = 0; q < 16; q++) tile[2 * (16 * g + q) + lr][lc] = v[q];
