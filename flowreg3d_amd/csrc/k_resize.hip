@@ -11,9 +11,12 @@ namespace fr3d {
 
 // axis 2: out (n0,n1,out_len); src rows of length n2.  A thread keeps the P taps of its output
 // column in registers and walks RX_ROWS rows with them (the taps depend on the column only), so the
-// table is read once per RX_ROWS outputs instead of once per output.
+// table is read once per RX_ROWS outputs instead of once per output.  PT > 0: the tap count is a
+// template constant (every pyramid step of eta = 0.8 needs <= 16 taps), so the gathers of two rows
+// are issued back to back without tap-count branches; PT == 0: generic loop for longer kernels.
 #define RX_ROWS 8
 #define RX_MAXP 16
+template <int PT>
 __global__ void __launch_bounds__(256)
 k_resize_x(const float *__restrict__ src, int cs, int co, long long rows, int n2, int out_len,
            const int *__restrict__ idx, const float *__restrict__ wt, int P, float *__restrict__ dst,
@@ -24,47 +27,39 @@ k_resize_x(const float *__restrict__ src, int cs, int co, long long rows, int n2
     const long long row0 = (long long)blockIdx.y * rpb;
     const int *ii = idx + (size_t)i * P;
     const float *ww = wt + (size_t)i * P;
-    if (P <= RX_MAXP) {
-        int tap[RX_MAXP];
-        float w[RX_MAXP];
+    if constexpr (PT > 0) {
+        int tap[PT];
+        float w[PT];
 #pragma unroll
-        for (int p = 0; p < RX_MAXP; p++) {
-            tap[p] = p < P ? ii[p] * cs : 0;
-            w[p] = p < P ? ww[p] : 0.0f;
+        for (int p = 0; p < PT; p++) {
+            tap[p] = ii[p] * cs;
+            w[p] = ww[p];
         }
-        if (rpb == RX_ROWS && row0 + RX_ROWS <= rows) {
-            // full group of rows: two rows per trip so that 2P gathers are in flight
-#pragma unroll 1
-            for (int q = 0; q < RX_ROWS; q += 2) {
-                const float *r0 = src + (size_t)(row0 + q) * n2 * cs + co;
-                const float *r1 = r0 + (size_t)n2 * cs;
-                float v0[RX_MAXP], v1[RX_MAXP];
+        long long q = 0;
+        for (; q + 2 <= rpb && row0 + q + 2 <= rows; q += 2) {  // two rows per trip: 2*PT gathers in flight
+            const float *r0 = src + (size_t)(row0 + q) * n2 * cs + co;
+            const float *r1 = r0 + (size_t)n2 * cs;
+            float v0[PT], v1[PT];
 #pragma unroll
-                for (int p = 0; p < RX_MAXP; p++) {
-                    v0[p] = p < P ? r0[tap[p]] : 0.0f;
-                    v1[p] = p < P ? r1[tap[p]] : 0.0f;
-                }
-                float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-                for (int p = 0; p < RX_MAXP; p++)
-                    if (p < P) {  // tap order and fp32 mul/add as the reference
-                        a0 += v0[p] * w[p];
-                        a1 += v1[p] * w[p];
-                    }
-                dst[(size_t)(row0 + q) * out_len + i] = a0;
-                dst[(size_t)(row0 + q + 1) * out_len + i] = a1;
+            for (int p = 0; p < PT; p++) {
+                v0[p] = r0[tap[p]];
+                v1[p] = r1[tap[p]];
             }
-            return;
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int p = 0; p < PT; p++) {  // tap order and fp32 mul/add as the reference
+                a0 += v0[p] * w[p];
+                a1 += v1[p] * w[p];
+            }
+            dst[(size_t)(row0 + q) * out_len + i] = a0;
+            dst[(size_t)(row0 + q + 1) * out_len + i] = a1;
         }
-        for (int q = 0; q < rpb; q++) {
-            const long long row = row0 + q;
-            if (row >= rows) break;
-            const float *r = src + (size_t)row * n2 * cs + co;
+        for (; q < rpb && row0 + q < rows; q++) {
+            const float *r = src + (size_t)(row0 + q) * n2 * cs + co;
             float a = 0.0f;
 #pragma unroll
-            for (int p = 0; p < RX_MAXP; p++)
-                if (p < P) a += r[tap[p]] * w[p];  // tap order and fp32 mul/add as the reference
-            dst[(size_t)row * out_len + i] = a;
+            for (int p = 0; p < PT; p++) a += r[tap[p]] * w[p];
+            dst[(size_t)(row0 + q) * out_len + i] = a;
         }
     } else {
         for (int q = 0; q < rpb; q++) {
@@ -81,6 +76,7 @@ k_resize_x(const float *__restrict__ src, int cs, int co, long long rows, int n2
 // axis 1 or 0 on planar data: src viewed as (outer, n, inner), dst (outer, out_len, inner).
 // blockIdx.y = output index along the axis, blockIdx.z = outer: the P taps and weights of a
 // workgroup are wave-uniform (scalar loads), the P gathers are independent coalesced row reads.
+template <int PT>
 __global__ void __launch_bounds__(256)
 k_resize_mid(const float *__restrict__ src, int n, long long inner, int out_len,
              const int *__restrict__ idx, const float *__restrict__ wt, int P,
@@ -94,18 +90,36 @@ k_resize_mid(const float *__restrict__ src, int n, long long inner, int out_len,
     const int *ii = idx + (size_t)i * P;
     const float *ww = wt + (size_t)i * P;
     float a = 0.0f;
-    // taps in groups of 8: the gathers of a group are independent and leave together, the sum keeps
-    // the reference's tap order (a one-tap-per-trip loop waits for every load in turn)
-    for (int p0 = 0; p0 < P; p0 += 8) {
-        float v[8];
+    if constexpr (PT > 0) {
+        float v[PT];
 #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = p0 + q < P ? base[(size_t)ii[p0 + q] * inner] : 0.0f;
+        for (int p = 0; p < PT; p++) v[p] = base[(size_t)ii[p] * inner];
 #pragma unroll
-        for (int q = 0; q < 8; q++)
-            if (p0 + q < P) a += v[q] * ww[p0 + q];
+        for (int p = 0; p < PT; p++) a += v[p] * ww[p];  // tap order as the reference
+    } else {
+        // taps in groups of 8: the gathers of a group are independent and leave together, the sum keeps
+        // the reference's tap order (a one-tap-per-trip loop waits for every load in turn)
+        for (int p0 = 0; p0 < P; p0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = p0 + q < P ? base[(size_t)ii[p0 + q] * inner] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (p0 + q < P) a += v[q] * ww[p0 + q];
+        }
     }
     dst[((size_t)o * out_len + i) * inner + x] = a;
 }
+
+// dispatch on the tap count: 1..16 as template constants, anything longer through the generic loop
+#define FR3D_TAP_SWITCH(P, CALL)                                                                          \
+    switch (P) {                                                                                           \
+        case 1: CALL(1); break;   case 2: CALL(2); break;   case 3: CALL(3); break;   case 4: CALL(4); break;   \
+        case 5: CALL(5); break;   case 6: CALL(6); break;   case 7: CALL(7); break;   case 8: CALL(8); break;   \
+        case 9: CALL(9); break;   case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
+        case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; case 16: CALL(16); break; \
+        default: CALL(0); break;                                                                           \
+    }
 
 void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0, int n1, int n2,
                         int axis, int out_len, const int *idx, const float *wt, int P, float *dst)
@@ -118,7 +132,9 @@ void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0
         int rpb = RX_ROWS;
         if (cdiv(rows, rpb) > 65535) rpb = cdiv(rows, 65535);
         dim3 grid(cdiv(out_len, 256), cdiv(rows, rpb));
-        hipLaunchKernelGGL(k_resize_x, grid, dim3(256), 0, st, src, cs, co, rows, n2, out_len, idx, wt, P, dst, rpb);
+#define FR3D_RX(PT) hipLaunchKernelGGL((k_resize_x<PT>), grid, dim3(256), 0, st, src, cs, co, rows, n2, out_len, idx, wt, P, dst, rpb)
+        FR3D_TAP_SWITCH(P, FR3D_RX)
+#undef FR3D_RX
     } else {
         FR3D_CHECK(cs == 1 && co == 0, "resize: y/z passes need planar input");
         long long outer = (axis == 1) ? n0 : 1;
@@ -128,8 +144,10 @@ void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0
         if (total == 0) return;
         FR3D_CHECK(out_len <= 65535 && outer <= 65535, "resize: axis length beyond the grid limits");
         const int bx = inner >= 256 ? 256 : cdiv(inner, 64) * 64;  // short rows: no idle waves
-        hipLaunchKernelGGL(k_resize_mid, dim3(cdiv(inner, bx), out_len, (unsigned)outer), dim3(bx), 0, st, src, n,
-                           inner, out_len, idx, wt, P, dst);
+        const dim3 grid(cdiv(inner, bx), out_len, (unsigned)outer);
+#define FR3D_RM(PT) hipLaunchKernelGGL((k_resize_mid<PT>), grid, dim3(bx), 0, st, src, n, inner, out_len, idx, wt, P, dst)
+        FR3D_TAP_SWITCH(P, FR3D_RM)
+#undef FR3D_RM
     }
 }
 
