@@ -38,7 +38,20 @@ k_gauss_pass(const TIN *__restrict__ in, int cs, int co, double nmin, double nde
     auto at = [&](int i) -> double { return ((double)in[(size_t)(base + (long long)i * st) * cs + co] - nmin) / nden; };
     const double *fw = w + radius;
     double tmp = at(l) * fw[0];
-    for (int jj = -radius; jj < 0; jj++) tmp += (at(reflect_hs(l + jj, n)) + at(reflect_hs(l - jj, n))) * fw[jj];
+    // four tap pairs per trip: their eight loads are independent and leave together; the sum keeps
+    // NI_Correlate1D's order (outermost pair first)
+    for (int j0 = -radius; j0 < 0; j0 += 4) {
+        double lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int jj = j0 + q < 0 ? j0 + q : -1;  // clamped: always a valid tap, discarded below
+            lo[q] = at(reflect_hs(l + jj, n));
+            hi[q] = at(reflect_hs(l - jj, n));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (j0 + q < 0) tmp += (lo[q] + hi[q]) * fw[j0 + q];
+    }
     out[e] = tmp;
 }
 
