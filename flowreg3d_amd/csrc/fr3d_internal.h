@@ -178,9 +178,14 @@ struct SorEntry {
     short kb0, njb;        // first k-tile, j-tiles per k-tile row (rows are left-aligned)
     short pad0, pad1;
 };
+#define SOR_LUT_SHIFT 6
 struct SorSched {
     std::vector<int> tau, t_lo, nt, first, ntiles;  // per launch
     SorEntry *entries = nullptr;                     // device, sum(nt) entries
+    // per launch, for every group of SOR_LUT_GROUP consecutive tiles the iteration (entry index) that
+    // holds the group's first tile: the kernel starts its search there instead of bisecting
+    std::vector<int> lut_first;                      // per launch: offset into `lut`
+    int *lut = nullptr;                              // device
     int by = 4;                                      // tile rows the schedule was built for
 };
 // Tile = 64 lanes along j x `by` rows.  Measured on MI355X: 4 rows at every level size (1 and 2 rows

@@ -34,20 +34,19 @@ namespace fr3d {
 
 template <typename R, typename S, int C, typename I>
 __global__ void __launch_bounds__(SOR_BX * SOR_BY_MAX)
-k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent)
+k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent,
+           const int *__restrict__ lut)
 {
     const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X, Yp = a.sk.Yp;
     const long long plane = a.sk.plane;
-    // blockIdx.x enumerates the tiles of all in-flight iterations (schedule built on the host):
-    // find the iteration by bisection on the tile prefix, then the tile inside its bounding box
+    // blockIdx.x enumerates the tiles of all in-flight iterations (schedule built on the host)
     const int vol = blockIdx.y;
     const int b = blockIdx.x;
-    int lo = 0, hi = nt - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (ent[mid].pre <= b) lo = mid;
-        else hi = mid - 1;
-    }
+    // find the iteration: the table gives the entry of the first tile of this tile group, a short
+    // forward scan does the rest (a bisection costs ~7 dependent scalar loads before the first
+    // vector load can be issued)
+    int lo = lut[b >> SOR_LUT_SHIFT];
+    while (lo + 1 < nt && ent[lo + 1].pre <= b) lo++;
     const SorEntry en = ent[lo];
     const int local = b - en.pre;
     const int t = t_lo + lo;
@@ -98,15 +97,15 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
 
 template <typename R, typename S>
 static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo, int nt, int ntiles,
-                        const SorEntry *ent, int by)
+                        const SorEntry *ent, const int *lut, int by)
 {
     dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, by);
     // 32-bit byte offsets whenever one volume's array stays below 4 GiB (every BASELINE size does)
     const bool narrow = (unsigned long long)a.sk.total * sizeof(S) < (1ull << 32);
 #define FR3D_SOR_CASE(CH)                                                                                      \
     case CH:                                                                                                   \
-        if (narrow) hipLaunchKernelGGL((k_sor_step<R, S, CH, unsigned>), grid, block, 0, st, a, tau, t_lo, nt, ent); \
-        else hipLaunchKernelGGL((k_sor_step<R, S, CH, size_t>), grid, block, 0, st, a, tau, t_lo, nt, ent);     \
+        if (narrow) hipLaunchKernelGGL((k_sor_step<R, S, CH, unsigned>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut); \
+        else hipLaunchKernelGGL((k_sor_step<R, S, CH, size_t>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut);     \
         break;
     switch (a.C) {
         FR3D_SOR_CASE(1)
@@ -135,6 +134,7 @@ SorSched build_sor_schedule(const Skew &sk, int T, int by)
     sc.by = by;
     const int S = sk.S, Z = sk.Z, Y = sk.Y, X = sk.X;
     std::vector<SorEntry> ent;
+    std::vector<int> lut;
     if (T <= 0) return sc;
     const int last = (S - 1) + 2 * (T - 1);
     for (int tau = 0; tau <= last; tau++) {
@@ -176,16 +176,30 @@ SorSched build_sor_schedule(const Skew &sk, int T, int by)
             ent.push_back(e);
         }
         sc.ntiles.push_back(pre);
+        // group table of this launch
+        sc.lut_first.push_back((int)lut.size());
+        const size_t e0 = (size_t)sc.first.back();
+        const int nte = t_hi - t_lo + 1;
+        int cur = 0;
+        for (int g = 0; (g << SOR_LUT_SHIFT) < pre; g++) {
+            const int b0 = g << SOR_LUT_SHIFT;
+            while (cur + 1 < nte && ent[e0 + cur + 1].pre <= b0) cur++;
+            lut.push_back(cur);
+        }
     }
     FR3D_HIP(hipMalloc((void **)&sc.entries, ent.size() * sizeof(SorEntry)));
     FR3D_HIP(hipMemcpy(sc.entries, ent.data(), ent.size() * sizeof(SorEntry), hipMemcpyHostToDevice));
+    FR3D_HIP(hipMalloc((void **)&sc.lut, std::max<size_t>(lut.size(), 1) * sizeof(int)));
+    FR3D_HIP(hipMemcpy(sc.lut, lut.data(), lut.size() * sizeof(int), hipMemcpyHostToDevice));
     return sc;
 }
 
 void free_sor_schedule(SorSched &s)
 {
     if (s.entries) (void)hipFree(s.entries);
+    if (s.lut) (void)hipFree(s.lut);
     s.entries = nullptr;
+    s.lut = nullptr;
 }
 
 template <typename S>
@@ -198,8 +212,9 @@ long long launch_sor(hipStream_t st, const SorArgsT<S> &a_in, bool fp64, const S
     for (size_t l = 0; l < sc.tau.size(); l++) {
         if (sc.ntiles[l] <= 0) continue;
         const SorEntry *ent = sc.entries + sc.first[l];
-        if (fp64 || sizeof(S) == 8) launch_step<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent, sc.by);
-        else launch_step<float, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent, sc.by);
+        const int *lut = sc.lut + sc.lut_first[l];
+        if (fp64 || sizeof(S) == 8) launch_step<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent, lut, sc.by);
+        else launch_step<float, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent, lut, sc.by);
         launches++;
     }
     return launches;
