@@ -100,3 +100,24 @@ def test_long_series_passes_through_the_device_in_windows(hip, monkeypatch):
                                      progress_callback=calls.append)
     assert sum(calls) == 9
     assert np.array_equal(fl1, fl2) and np.array_equal(reg1, reg2)
+
+
+def test_repeated_batches_are_deterministic_and_do_not_grow_device_memory(hip):
+    """A long recording is many process_batch calls on one engine: same input -> same bits, and the
+    workspace stops growing after the first call (all staging buffers are released again)."""
+    import torch
+    from flowreg3d_amd.executor import HipExecutor3D
+    fixed, batch = _series(T=10, shape=(16, 24, 32))
+    w0 = np.zeros(batch.shape[1:4] + (3,), np.float32)
+    fp = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=15, min_level=0, levels=3, eta=0.8,
+              a_smooth=1.0, a_data=0.45)
+    with HipExecutor3D() as ex:
+        reg0, fl0 = ex.process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=fp)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        for _ in range(5):
+            reg, fl = ex.process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=fp)
+            assert np.array_equal(fl, fl0) and np.array_equal(reg, reg0)
+        torch.cuda.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), (free0, free1)  # no growth beyond allocator granularity
