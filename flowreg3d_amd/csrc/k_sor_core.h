@@ -39,7 +39,9 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
 {
     if (upd) {
         R M11 = 0, M22 = 0, M33 = 0, M12 = 0, M13 = 0, M23 = 0, bu = 0, bv = 0, bw = 0;
-#pragma unroll
+        // one channel at a time: unrolling over channels keeps 12C factors live and costs the ordinary
+        // iterations (4 of 5) their occupancy
+#pragma unroll 1
         for (int c = 0; c < C; c++) {
             // psi_data update (level_solver_3d.py:356-377) from the increments of iteration t-1.
             // The quadratic form is evaluated as the sum of three squared residuals of the tensor's
