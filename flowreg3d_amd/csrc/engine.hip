@@ -58,6 +58,9 @@ static std::vector<Level> make_schedule(int p, int m, int n, double eta, int lev
         L.z = (int)py_round((double)p * std::pow(eta, (double)std::min(i, mlz)));
         L.y = (int)py_round((double)m * std::pow(eta, (double)std::min(i, mly)));
         L.x = (int)py_round((double)n * std::pow(eta, (double)std::min(i, mlx)));
+        // e.g. an axis of length 1 with eta = 0.5: round(0.5) = 0.  The reference fails here as well
+        // (ZeroDivisionError in imresize_fused_gauss_cubic3D, util/resize_util_3D.py:116-128)
+        FR3D_CHECK(L.z >= 1 && L.y >= 1 && L.x >= 1, "pyramid level with a zero-sized axis (eta too small for this volume)");
         out.push_back(L);
     }
     return out;

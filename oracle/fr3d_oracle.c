@@ -772,6 +772,13 @@ int fr3d_oracle_get_displacement(const double *fixed, const double *moving, int 
     schedule_levels(p, m, n, eta, levels, &min_level, &mlz, &mly, &mlx);
     const int top = imax(mlx, imax(mly, mlz));
     const size_t nfull = (size_t)p * m * n;
+    /* a level whose rounded size is 0 (axis of length 1 with eta = 0.5, ...) makes the reference
+     * raise ZeroDivisionError in its resampler (util/resize_util_3D.py:116-128): report bad input */
+    for (int i = top; i >= min_level; i--) {
+        int ls[3];
+        level_size_of(p, m, n, eta, i, mlz, mly, mlx, ls);
+        if (ls[0] < 1 || ls[1] < 1 || ls[2] < 1) return 1;
+    }
 
     /* :343-350 */
     double *init[3];

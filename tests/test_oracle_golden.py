@@ -104,3 +104,13 @@ def test_get_displacement_vs_reference(oracle, name, tol_mean, tol_max):
     assert flow.shape == g["flow"].shape and flow.dtype == np.float64
     d = np.linalg.norm(flow - g["flow"], axis=-1)
     assert d.mean() < tol_mean and d.max() < tol_max, (d.mean(), d.max())
+
+
+def test_zero_sized_pyramid_level_is_rejected():
+    """round(1 * 0.5) == 0: the reference raises ZeroDivisionError in its resampler for such a level
+    (util/resize_util_3D.py:116-128); the restatement reports bad input instead of reading past arrays."""
+    from oracle import oracle
+    fixed = np.random.default_rng(0).random((1, 6, 70)).astype(np.float32)
+    with pytest.raises(ValueError):
+        oracle.get_displacement(fixed, fixed, alpha=(1, 1, 1), update_lag=5, iterations=4, min_level=3, levels=9,
+                                eta=0.5, a_smooth=1.0, a_data=0.45)

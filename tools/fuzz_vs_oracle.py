@@ -1,0 +1,71 @@
+"""Randomised shapes / parameters: GPU get_displacement (fp64 solver storage) against the CPU oracle.
+usage (GPU box): python tools/fuzz_vs_oracle.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import flowreg3d_amd as fr
+from flowreg3d_amd import _lib
+from oracle import oracle
+from scipy.ndimage import gaussian_filter
+
+
+
+def run(n_cases=40, seed=0, verbose=True):
+    """-> (number of failing cases, worst mean EPE relative to max(1, |flow|max))"""
+    say = print if verbose else (lambda *a, **k: None)
+    rng = np.random.default_rng(seed)
+    _lib.init()
+    worst = 0.0
+    bad = 0
+    for case in range(n_cases):
+        shape = tuple(int(v) for v in rng.choice([1, 2, 3, 5, 6, 7, 9, 16, 23, 31, 40, 65, 70], size=3))
+        if np.prod(shape) > 120000:
+            shape = (shape[0] % 24 + 1, shape[1], shape[2])
+        C = int(rng.choice([1, 1, 2, 3]))
+        def vol():
+            a = gaussian_filter(rng.random(shape), 1.0, mode="reflect")
+            return ((a - a.min()) / (a.max() - a.min() + 1e-12)).astype(np.float32)
+        fixed = np.stack([vol() for _ in range(C)], -1)
+        moving = np.stack([0.97 * gaussian_filter(fixed[..., c], 0.6) + 0.02 for c in range(C)], -1).astype(np.float32)
+        kw = dict(alpha=tuple(float(x) for x in rng.uniform(0.1, 2.0, 3)), update_lag=int(rng.integers(1, 7)),
+                  iterations=int(rng.integers(0, 25)), min_level=int(rng.integers(0, 4)), levels=int(rng.integers(1, 12)),
+                  eta=float(rng.choice([0.5, 0.75, 0.8, 0.9])), a_smooth=float(rng.choice([1.0, 1.0, 0.5])),
+                  a_data=float(rng.choice([0.45, 1.0, 0.3])))
+        if C > 1 and rng.random() < 0.5:
+            kw["weight"] = rng.uniform(0.2, 1.0, C)
+        uvw = None
+        if rng.random() < 0.3:
+            uvw = (0.3 * rng.standard_normal(shape + (3,))).astype(np.float32)
+        try:
+            try:
+                want = oracle.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), **kw)
+            except ValueError:
+                # input the reference itself rejects (e.g. a pyramid level rounded to size 0): the GPU path must refuse too
+                try:
+                    fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=2, **kw)
+                    bad += 1
+                    say("BAD case %2d shape %s: oracle rejects, GPU path accepted" % (case, shape), flush=True)
+                except (ValueError, RuntimeError):
+                    say("ok  case %2d shape %s C=%d: rejected by both" % (case, shape, C), flush=True)
+                continue
+            got = fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=2, **kw)
+            d = np.linalg.norm(got - want, axis=-1)
+            scale = max(1.0, float(np.abs(want).max()))
+            ok = np.isfinite(got).all() and d.mean() < 1e-4 * scale
+            worst = max(worst, d.mean() / scale)
+            if not ok:
+                bad += 1
+            say("%s case %2d shape %s C=%d %s uvw=%s: mean %.2e max %.2e" % ("ok " if ok else "BAD", case, shape, C,
+                  {k: (np.round(v, 3).tolist() if hasattr(v, "__len__") else v) for k, v in kw.items()}, uvw is not None,
+                  d.mean(), d.max()), flush=True)
+        except Exception as e:  # noqa
+            bad += 1
+            say("EXC case %d shape %s C=%d %s: %r" % (case, shape, C, kw, e), flush=True)
+    return bad, worst
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    sd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad, worst = run(n, sd)
+    print("cases %d bad %d worst scaled mean EPE %.2e" % (n, bad, worst))
