@@ -28,3 +28,11 @@ def test_level_rounded_to_zero_is_rejected_like_the_reference(hip, oracle):
         oracle.get_displacement(fixed, fixed, **kw)
     with pytest.raises((ValueError, RuntimeError)):
         hip.get_displacement(fixed, fixed, **kw)
+
+
+def test_random_stage_inputs_match_the_oracle(hip, oracle):
+    """Resampler (arbitrary source/target sizes, bit-exact), cubic and linear warp (displacements from
+    sub-voxel to far outside the volume), 5^3 median on shapes down to a single voxel."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_stages
+    assert fuzz_stages.run(n_cases=40, seed=5, verbose=False) == 0
