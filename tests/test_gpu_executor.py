@@ -121,3 +121,19 @@ def test_repeated_batches_are_deterministic_and_do_not_grow_device_memory(hip):
         torch.cuda.synchronize()
         free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < (8 << 20), (free0, free1)  # no growth beyond allocator granularity
+
+
+def test_concurrent_callers_are_serialised_correctly(hip, oracle):
+    """The reference's ThreadingExecutor3D calls get_displacement_func from several threads at once
+    (parallelization/threading_3d.py:209-225); the engine serialises them on its mutex and every
+    caller must get the result of its own input."""
+    from concurrent.futures import ThreadPoolExecutor
+    fixed, batch = _series(T=6, shape=(12, 18, 20))
+    fp = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=10, min_level=0, levels=2, eta=0.8,
+              a_smooth=1.0, a_data=0.45)
+    serial = [hip.get_displacement(fixed[..., 0], batch[t, ..., 0], **fp) for t in range(6)]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        threaded = list(pool.map(lambda t: hip.get_displacement(fixed[..., 0], batch[t, ..., 0], **fp), range(6)))
+    for a, b in zip(serial, threaded):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(serial[0], serial[5])
