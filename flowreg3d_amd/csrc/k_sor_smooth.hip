@@ -55,6 +55,9 @@ __device__ double psi_smooth_at(const SmoothView<S> &v, int k, int j, int i)
         g += dz * dz;
     }
     if (g < 0.0) g = 0.0;
+    // fp32 storage: psi_s is rounded to fp32 when stored or used, so a 1-ulp powf is enough (the fp64
+    // pow is a ~600-instruction dependent chain per voxel and iteration); fp64 storage keeps pow
+    if (sizeof(S) == 4) return v.a_smooth * (double)powf((float)(g + 1e-5), (float)(v.a_smooth - 1.0));
     return v.a_smooth * pow(g + 1e-5, v.a_smooth - 1.0);
 }
 
@@ -113,27 +116,43 @@ k_sor_smooth(const SmoothArgs<S> a, int tau, int t_lo)
     const int ni[6] = {i, i, i, i, i - 1, i + 1};
     const double sc[6] = {a.az, a.az, a.ay, a.ay, a.ax, a.ax};
     const bool newer[6] = {true, false, true, false, true, false};  // minus side already swept
+    // psi_s and the neighbour terms of the six neighbours.  Inside the volume: loads at the (clamped)
+    // neighbour position, all unconditional.  Ghost neighbours need psi_s evaluated on the fly, which
+    // is expensive and diverges; per axis at most one of the two neighbours is a ghost (both only
+    // when that axis has length 1), so it is evaluated once per axis instead of once per neighbour.
+    double psn[6], term[6][3];
+    bool inside[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        inside[q] = nk[q] >= 0 && nk[q] < Z && nj[q] >= 0 && nj[q] < Y && ni[q] >= 0 && ni[q] < X;
+        const int kc = min(max(nk[q], 0), Z - 1), jc = min(max(nj[q], 0), Y - 1), ic = min(max(ni[q], 0), X - 1);
+        const size_t o = (size_t)sk_index(X, v.Yp, v.plane, kc, jc, ic);
+        psn[q] = (double)a.Ps[o];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double nb = (double)v.U[c][o] + (double)(newer[q] ? Dn[c][o] : Do[c][o]) - u0[c];
+            // ghost: u is edge-padded (u_nb = u_c) and du holds the Neumann copy of the voxel's own
+            // previous increment (set_boundary_3d ran right before this sweep)
+            term[q][c] = inside[q] ? nb : (u0[c] + d0[c]) - u0[c];
+        }
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+        const int qm = 2 * ax, qp = 2 * ax + 1;
+        if (!inside[qm] || !inside[qp]) {
+            const int g = !inside[qm] ? qm : qp;
+            const double val = psi_smooth_at(v, nk[g], nj[g], ni[g]);
+            if (!inside[qm]) psn[qm] = val;
+            else psn[qp] = val;
+            if (!inside[qm] && !inside[qp]) psn[qp] = psi_smooth_at(v, nk[qp], nj[qp], ni[qp]);  // axis of length 1
+        }
+    }
     double num[3] = {0.0, 0.0, 0.0}, den = 0.0;
 #pragma unroll
     for (int q = 0; q < 6; q++) {
-        const bool inside = nk[q] >= 0 && nk[q] < Z && nj[q] >= 0 && nj[q] < Y && ni[q] >= 0 && ni[q] < X;
-        double psn, term[3];
-        if (inside) {
-            const size_t o = (size_t)sk_index(X, v.Yp, v.plane, nk[q], nj[q], ni[q]);
-            psn = (double)a.Ps[o];
+        const double tmp = 0.5 * (ps_c + psn[q]) * sc[q];
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-                term[c] = (double)v.U[c][o] + (double)(newer[q] ? Dn[c][o] : Do[c][o]) - u0[c];
-        } else {
-            // ghost: u is edge-padded (u_nb = u_c) and du holds the Neumann copy of the voxel's own
-            // previous increment (set_boundary_3d ran right before this sweep)
-            psn = psi_smooth_at(v, nk[q], nj[q], ni[q]);
-#pragma unroll
-            for (int c = 0; c < 3; c++) term[c] = (u0[c] + d0[c]) - u0[c];
-        }
-        const double tmp = 0.5 * (ps_c + psn) * sc[q];
-#pragma unroll
-        for (int c = 0; c < 3; c++) num[c] += tmp * term[c];
+        for (int c = 0; c < 3; c++) num[c] += tmp * term[q][c];
         den += tmp;
     }
 
