@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="volumes solved in lock step per GPU (shared launches); 0 = 8, or 4 at 512^3 "
                          "where 8 slabs of solver operands (43 GB each) would not fit in 288 GB")
-    ap.add_argument("--condition", type=float, default=15.0,
+    ap.add_argument("--condition", type=float, default=30.0,
                     help="seconds of untimed warm-up work before the timed steps (0 = only the W warm-up steps)")
     args = ap.parse_args()
 
@@ -189,7 +189,7 @@ def main():
         # steps use has been touched (fresh device memory is slower on first use); the volumes it
         # borrows from the timed range are recomputed inside the timed region
         run(0, max(W, batch_vols), False)
-        # An idle MI355X needs ~15 s of load before its memory system runs at full rate (the SOR
+        # An idle MI355X needs 15 s and more of load before its memory system runs at full rate (the SOR
         # kernel measures 3.5 TB/s in the first seconds of a fresh box and 3.85 TB/s from then on,
         # whatever the binary): keep repeating the warm-up batch, untimed, for --condition seconds
         # so that the timed steps see the steady state a long series runs in.
