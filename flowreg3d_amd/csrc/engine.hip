@@ -217,13 +217,14 @@ struct Engine {
     hipStream_t st = nullptr;
     std::map<std::string, DevBuf> bufs;
     std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
-    std::map<std::tuple<int, int, int, int>, SorSched> scheds;     // (Z,Y,X,iterations) of a level
+    std::map<std::tuple<int, int, int, int, int>, SorSched> scheds;  // (Z,Y,X,iterations,lag) of a level
 
-    const SorSched &sched(const Skew &sk, int iterations)
+    const SorSched &sched(const Skew &sk, int iterations, int lag = 2)
     {
-        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations);
+        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, lag);
         auto it = scheds.find(key);
-        if (it == scheds.end()) it = scheds.emplace(key, build_sor_schedule(sk, iterations, sor_tile_rows(sk))).first;
+        if (it == scheds.end())
+            it = scheds.emplace(key, build_sor_schedule(sk, iterations, sor_tile_rows(sk), lag)).first;
         return it->second;
     }
     // profiling
@@ -534,7 +535,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 sa.iterations = p.iterations;
                 sa.update_lag = p.update_lag;
                 sa.S_planes = sk.S;
-                long long n = launch_sor_smooth<S>(e.st, sa);
+                long long n = launch_sor_smooth<S>(e.st, sa, e.sched(sk, p.iterations, SM_LAG));
                 if (p.iterations > 0)
                     FR3D_HIP(hipMemcpyAsync(dbuf + (size_t)b * a.vsD, sa.D[(p.iterations - 1) % 3][0], ns * 3 * sizeof(S),
                                             hipMemcpyDeviceToDevice, e.st));
@@ -1304,7 +1305,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
         }
         sa.ax = a.ax; sa.ay = a.ay; sa.az = a.az;
         sa.C = C; sa.iterations = iterations; sa.update_lag = update_lag; sa.S_planes = sk.S;
-        launch_sor_smooth<float>(e.st, sa);
+        launch_sor_smooth<float>(e.st, sa, e.sched(sk, iterations, SM_LAG));
         if (iterations > 0)
             FR3D_HIP(hipMemcpyAsync(db, sa.D[(iterations - 1) % 3][0], ns * 3 * 4, hipMemcpyDeviceToDevice, e.st));
     }

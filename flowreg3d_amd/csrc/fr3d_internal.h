@@ -125,8 +125,9 @@ struct SmoothArgs {
     int C, iterations, update_lag, S_planes;
 };
 
+struct SorSched;
 template <typename S>
-long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a);
+long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSched &sched);
 
 // ---- launchers (each enqueues on `st`, no synchronisation) ------------------------------------
 
@@ -187,11 +188,15 @@ struct SorSched {
     std::vector<int> lut_first;                      // per launch: offset into `lut`
     int *lut = nullptr;                              // device
     int by = 4;                                      // tile rows the schedule was built for
+    int lag = 2;                                     // hyperplanes between consecutive in-flight iterations
+    std::vector<int> launch_of_tau;                  // tau -> index into the per-launch vectors, -1 = nothing to do
 };
 // Tile = 64 lanes along j x `by` rows.  Measured on MI355X: 4 rows at every level size (1 and 2 rows
 // are within 2 % since the neighbour loads became unconditional); FR3D_SOR_BY overrides.
 int sor_tile_rows(const Skew &sk);
-SorSched build_sor_schedule(const Skew &sk, int iterations, int by);
+// iteration t works on hyperplane tau - lag*t in launch tau (lag 2: a_smooth == 1 kernel; lag 4 = SM_LAG:
+// the a_smooth != 1 kernels, whose P-stage and sweep share one schedule two launches apart)
+SorSched build_sor_schedule(const Skew &sk, int iterations, int by, int lag = 2);
 void free_sor_schedule(SorSched &s);
 // Runs all `iterations` pipelined hyperplane steps.  Returns the number of kernel launches.
 template <typename S>

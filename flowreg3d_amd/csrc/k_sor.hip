@@ -128,28 +128,31 @@ int sor_tile_rows(const Skew &sk)
     return 4;
 }
 
-SorSched build_sor_schedule(const Skew &sk, int T, int by)
+SorSched build_sor_schedule(const Skew &sk, int T, int by, int lag)
 {
     SorSched sc;
     sc.by = by;
+    sc.lag = lag;
     const int S = sk.S, Z = sk.Z, Y = sk.Y, X = sk.X;
     std::vector<SorEntry> ent;
     std::vector<int> lut;
     if (T <= 0) return sc;
-    const int last = (S - 1) + 2 * (T - 1);
+    const int last = (S - 1) + lag * (T - 1);
+    sc.launch_of_tau.assign((size_t)last + 1, -1);
     for (int tau = 0; tau <= last; tau++) {
         int t_lo = tau - (S - 1);
-        t_lo = t_lo <= 0 ? 0 : (t_lo + 1) / 2;
-        int t_hi = tau / 2;
+        t_lo = t_lo <= 0 ? 0 : (t_lo + lag - 1) / lag;
+        int t_hi = tau / lag;
         if (t_hi > T - 1) t_hi = T - 1;
         if (t_lo > t_hi) continue;
+        sc.launch_of_tau[tau] = (int)sc.tau.size();
         sc.tau.push_back(tau);
         sc.t_lo.push_back(t_lo);
         sc.nt.push_back(t_hi - t_lo + 1);
         sc.first.push_back((int)ent.size());
         int pre = 0;
         for (int t = t_lo; t <= t_hi; t++) {
-            const int s = tau - 2 * t;
+            const int s = tau - lag * t;
             // valid rows of hyperplane s: k in [klo,khi]; row (s,k) holds r = s-k, j in
             // [jm(r), min(Y-1,r)], stored left-aligned, so tiles start at 0 and the row count of
             // j-tiles is set by the longest row

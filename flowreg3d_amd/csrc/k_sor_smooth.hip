@@ -32,13 +32,17 @@ __device__ __forceinline__ double uu_at(const SmoothView<S> &v, int c, int k, in
     const int jc = j < 0 ? 0 : (j >= v.Y ? v.Y - 1 : j);
     const int ic = i < 0 ? 0 : (i >= v.X ? v.X - 1 : i);
     const size_t o = (size_t)sk_index(v.X, v.Yp, v.plane, kc, jc, ic);
-    return (double)v.U[c][o] + (double)(ghost ? v.Dm2[c][o] : v.Dm1[c][o]);
+    // both buffers are read and the value is selected: selecting the POINTER (v.Dm2[c] vs v.Dm1[c]) makes
+    // the compiler index the view structure with a run-time offset, which pins it in scratch memory
+    // and degrades every access through it to a flat load
+    const double d1 = (double)v.Dm1[c][o], d2 = (double)v.Dm2[c][o];
+    return (double)v.U[c][o] + (ghost ? d2 : d1);
 }
 
 // nonlinearity_smoothness_3d at one padded position (indices clamped to the padded array,
 // differences always divided by 2h, :280-311)
 template <typename S>
-__device__ double psi_smooth_at(const SmoothView<S> &v, int k, int j, int i)
+__device__ __forceinline__ double psi_smooth_at(const SmoothView<S> &v, int k, int j, int i)
 {
     auto cl = [](int q, int n) { return q < -1 ? -1 : (q > n ? n : q); };
     const int km = cl(k - 1, v.Z), kp = cl(k + 1, v.Z);
@@ -61,51 +65,114 @@ __device__ double psi_smooth_at(const SmoothView<S> &v, int k, int j, int i)
     return v.a_smooth * pow(g + 1e-5, v.a_smooth - 1.0);
 }
 
-// P-stage: psi_s^t on hyperplane q for every in-flight t (grid.z)
+// a.D[m][c] for a wave-uniform m in 0..2, chosen with selects: indexing the kernel argument with a
+// run-time value would move the pointer table to scratch memory and turn every access through it
+// into a flat load
 template <typename S>
-__global__ void __launch_bounds__(256)
-k_psi_smooth(const SmoothArgs<S> a, int tau, int t_lo)
+__device__ __forceinline__ S *pick_buffer(const SmoothArgs<S> &a, int m, int c)
 {
-    const int t = t_lo + blockIdx.z;
-    const int q = tau + 2 - SM_LAG * t;
-    if (t >= a.iterations || q < 0 || q >= a.S_planes) return;
-    const int k = blockIdx.y * blockDim.y + threadIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.view.Z || j >= a.view.Y) return;
-    const int i = q - k - j;
-    if (i < 0 || i >= a.view.X) return;
+    return m == 0 ? a.D[0][c] : (m == 1 ? a.D[1][c] : a.D[2][c]);
+}
+
+// Thread -> voxel mapping shared by both kernels: the tile schedule of k_sor.hip with SM_LAG planes
+// between iterations (blockIdx.x enumerates the 64 x blockDim.y tiles of all in-flight iterations,
+// rows are the left-aligned skewed rows, lanes run along j).  Returns false for lanes without a voxel.
+struct SmoothPos {
+    int t, s, k, j, i;
+    size_t c0, xm, xp, ym, yp, zm, zp;  // element offsets of the voxel and its six neighbours
+};
+template <typename S>
+__device__ __forceinline__ bool smooth_locate(const SmoothArgs<S> &a, int b, int tau, int t_lo, int nt,
+                                              const SorEntry *__restrict__ ent, const int *__restrict__ lut,
+                                              SmoothPos &p)
+{
+    const int Z = a.view.Z, Y = a.view.Y, X = a.view.X, Yp = a.view.Yp;
+    const long long plane = a.view.plane;
+    int lo = lut[b >> SOR_LUT_SHIFT];
+    while (lo + 1 < nt && ent[lo + 1].pre <= b) lo++;
+    const SorEntry en = ent[lo];
+    const int local = b - en.pre;
+    p.t = t_lo + lo;
+    p.s = tau - SM_LAG * p.t;
+    p.k = (en.kb0 + local / en.njb) * (int)blockDim.y + threadIdx.y;
+    if (p.k >= Z) return false;
+    const int r = p.s - p.k;
+    const int jm0 = sk_jm(X, r);
+    const int jj = (local % en.njb) * 64 + threadIdx.x;
+    p.j = jj + jm0;
+    p.i = r - p.j;
+    if (r < 0 || p.j >= Y || p.i < 0) return false;
+    const long long c0 = (long long)p.s * plane + (long long)p.k * Yp + jj;
+    const long long d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
+    p.c0 = (size_t)c0;
+    p.xm = (size_t)(c0 - plane + d1);
+    p.xp = (size_t)(c0 + plane + d2);
+    p.ym = (size_t)(c0 - plane + d1 - 1);
+    p.yp = (size_t)(c0 + plane + d2 + 1);
+    p.zm = (size_t)(c0 - plane - Yp);
+    p.zp = (size_t)(c0 + plane + Yp);
+    return true;
+}
+
+// P-stage: psi_s^t on hyperplane q = tau - 4t (the caller passes tau = step + 2)
+template <typename S>
+__device__ __forceinline__ void psi_body(const SmoothArgs<S> &a, int b, int tau, int t_lo, int nt,
+                                         const SorEntry *__restrict__ ent, const int *__restrict__ lut)
+{
+    SmoothPos p;
+    if (!smooth_locate(a, b, tau, t_lo, nt, ent, lut, p)) return;
     SmoothView<S> v = a.view;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        v.Dm1[c] = a.D[(t + 2) % 3][c];  // (t-1) mod 3
-        v.Dm2[c] = a.D[(t + 1) % 3][c];  // (t-2) mod 3
+        v.Dm1[c] = pick_buffer(a, (p.t + 2) % 3, c);  // (t-1) mod 3
+        v.Dm2[c] = pick_buffer(a, (p.t + 1) % 3, c);  // (t-2) mod 3
     }
-    a.Ps[(size_t)sk_index(v.X, v.Yp, v.plane, k, j, i)] = (S)psi_smooth_at(v, k, j, i);
+    double ps;
+    if (p.k > 0 && p.k < v.Z - 1 && p.j > 0 && p.j < v.Y - 1 && p.i > 0 && p.i < v.X - 1) {
+        // interior: no clamping, no ghosts -- psi_smooth_at with the six neighbours at row-uniform offsets
+        double g = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const S *U = v.U[c], *D = v.Dm1[c];
+            const double xp = (double)U[p.xp] + (double)D[p.xp], xm = (double)U[p.xm] + (double)D[p.xm];
+            const double yp = (double)U[p.yp] + (double)D[p.yp], ym = (double)U[p.ym] + (double)D[p.ym];
+            const double zp = (double)U[p.zp] + (double)D[p.zp], zm = (double)U[p.zm] + (double)D[p.zm];
+            const double dx = (xp - xm) / (2.0 * v.hx);
+            const double dy = (yp - ym) / (2.0 * v.hy);
+            const double dz = (zp - zm) / (2.0 * v.hz);
+            g += dx * dx;
+            g += dy * dy;
+            g += dz * dz;
+        }
+        if (g < 0.0) g = 0.0;
+        if (sizeof(S) == 4) ps = v.a_smooth * (double)powf((float)(g + 1e-5), (float)(v.a_smooth - 1.0));
+        else ps = v.a_smooth * pow(g + 1e-5, v.a_smooth - 1.0);
+    } else {
+        ps = psi_smooth_at(v, p.k, p.j, p.i);  // surface voxel: clamped indices and ghost values
+    }
+    a.Ps[p.c0] = (S)ps;
 }
 
 // sweep: iteration t on hyperplane s = tau - 4t
 template <typename S, int C>
-__global__ void __launch_bounds__(256)
-k_sor_smooth(const SmoothArgs<S> a, int tau, int t_lo)
+__device__ __forceinline__ void sweep_body(const SmoothArgs<S> &a, int b, int tau, int t_lo, int nt,
+                                           const SorEntry *__restrict__ ent, const int *__restrict__ lut)
 {
-    const int t = t_lo + blockIdx.z;
-    const int s = tau - SM_LAG * t;
-    if (t >= a.iterations || s < 0 || s >= a.S_planes) return;
+    SmoothPos p;
+    if (!smooth_locate(a, b, tau, t_lo, nt, ent, lut, p)) return;
     const int Z = a.view.Z, Y = a.view.Y, X = a.view.X;
-    const int k = blockIdx.y * blockDim.y + threadIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Z || j >= Y) return;
-    const int i = s - k - j;
-    if (i < 0 || i >= X) return;
+    const int t = p.t, k = p.k, j = p.j, i = p.i;
     SmoothView<S> v = a.view;
-    S *const *Dn = a.D[t % 3];                 // new values (this iteration)
-    const S *const *Do = a.D[(t + 2) % 3];     // old values (iteration t-1)
+    S *Dn[3];        // new values (this iteration)
+    const S *Do[3];  // old values (iteration t-1)
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        v.Dm1[c] = a.D[(t + 2) % 3][c];
-        v.Dm2[c] = a.D[(t + 1) % 3][c];
+        Dn[c] = pick_buffer(a, t % 3, c);
+        Do[c] = pick_buffer(a, (t + 2) % 3, c);
+        v.Dm1[c] = Do[c];
+        v.Dm2[c] = pick_buffer(a, (t + 1) % 3, c);
     }
-    const size_t c0 = (size_t)sk_index(X, v.Yp, v.plane, k, j, i);
+    const size_t c0 = p.c0;
     const double d0[3] = {(double)Do[0][c0], (double)Do[1][c0], (double)Do[2][c0]};
     const double u0[3] = {(double)v.U[0][c0], (double)v.U[1][c0], (double)v.U[2][c0]};
     const double ps_c = (double)a.Ps[c0];
@@ -114,19 +181,18 @@ k_sor_smooth(const SmoothArgs<S> a, int tau, int t_lo)
     const int nk[6] = {k - 1, k + 1, k, k, k, k};
     const int nj[6] = {j, j, j - 1, j + 1, j, j};
     const int ni[6] = {i, i, i, i, i - 1, i + 1};
+    const size_t off[6] = {p.zm, p.zp, p.ym, p.yp, p.xm, p.xp};
+    const bool inside[6] = {k > 0, k < Z - 1, j > 0, j < Y - 1, i > 0, i < X - 1};
     const double sc[6] = {a.az, a.az, a.ay, a.ay, a.ax, a.ax};
     const bool newer[6] = {true, false, true, false, true, false};  // minus side already swept
-    // psi_s and the neighbour terms of the six neighbours.  Inside the volume: loads at the (clamped)
-    // neighbour position, all unconditional.  Ghost neighbours need psi_s evaluated on the fly, which
-    // is expensive and diverges; per axis at most one of the two neighbours is a ghost (both only
-    // when that axis has length 1), so it is evaluated once per axis instead of once per neighbour.
+    // psi_s and the neighbour terms.  Inside the volume: loads at the neighbour's offset (a ghost
+    // reads c0 instead), all unconditional.  Ghost neighbours need psi_s evaluated on the fly, which is
+    // expensive and diverges; per axis at most one of the two neighbours is a ghost (both only when
+    // that axis has length 1), so it is evaluated once per axis instead of once per neighbour.
     double psn[6], term[6][3];
-    bool inside[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) {
-        inside[q] = nk[q] >= 0 && nk[q] < Z && nj[q] >= 0 && nj[q] < Y && ni[q] >= 0 && ni[q] < X;
-        const int kc = min(max(nk[q], 0), Z - 1), jc = min(max(nj[q], 0), Y - 1), ic = min(max(ni[q], 0), X - 1);
-        const size_t o = (size_t)sk_index(X, v.Yp, v.plane, kc, jc, ic);
+        const size_t o = inside[q] ? off[q] : c0;
         psn[q] = (double)a.Ps[o];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -140,8 +206,8 @@ k_sor_smooth(const SmoothArgs<S> a, int tau, int t_lo)
     for (int ax = 0; ax < 3; ax++) {
         const int qm = 2 * ax, qp = 2 * ax + 1;
         if (!inside[qm] || !inside[qp]) {
-            const int g = !inside[qm] ? qm : qp;
-            const double val = psi_smooth_at(v, nk[g], nj[g], ni[g]);
+            const bool gm = !inside[qm];  // which neighbour of the axis is the ghost (selects, no indexed arrays)
+            const double val = psi_smooth_at(v, gm ? nk[qm] : nk[qp], gm ? nj[qm] : nj[qp], gm ? ni[qm] : ni[qp]);
             if (!inside[qm]) psn[qm] = val;
             else psn[qp] = val;
             if (!inside[qm] && !inside[qp]) psn[qp] = psi_smooth_at(v, nk[qp], nj[qp], ni[qp]);  // axis of length 1
@@ -210,50 +276,58 @@ k_sor_smooth(const SmoothArgs<S> a, int tau, int t_lo)
     Dn[2][c0] = (S)dw1;
 }
 
-template <typename S>
-long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a)
+// One launch per step: the first `ntP` workgroups are P-stage tiles (psi_s^t on plane n - 4t), the rest
+// sweep tiles (iteration t on plane n - 2 - 4t).  Within a step the two are independent: the sweep
+// reads psi_s of planes finished in earlier steps, the P-stage reads increments swept in earlier steps.
+struct StepPart {
+    int tau, t_lo, nt, ntiles;
+    const SorEntry *ent;
+    const int *lut;
+};
+template <typename S, int C>
+__global__ void __launch_bounds__(256)
+k_smooth_step(const SmoothArgs<S> a, StepPart P, StepPart W)
 {
-    const int T = a.iterations, Sp = a.S_planes;
-    if (T <= 0) return 0;
-    const int Z = a.view.Z, Y = a.view.Y;
-    const dim3 block(64, 4);
-    const int gx = cdiv(Y, 64), gy = cdiv(Z, 4);
+    const int b = blockIdx.x;
+    if (b < P.ntiles) psi_body<S>(a, b, P.tau, P.t_lo, P.nt, P.ent, P.lut);
+    else sweep_body<S, C>(a, b - P.ntiles, W.tau, W.t_lo, W.nt, W.ent, W.lut);
+}
+
+// One schedule (SM_LAG planes between iterations) serves both parts: step n runs the P-stage with
+// tau = n and the sweep with tau = n - 2, i.e. psi_s^t is two planes ahead of sweep t.
+template <typename S>
+long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSched &sc)
+{
+    if (a.iterations <= 0) return 0;
+    FR3D_CHECK(sc.lag == SM_LAG, "internal: smooth solver needs the lag-4 schedule");
+    const dim3 block(64, sc.by);
     long long launches = 0;
-    const int last = (Sp - 1) + SM_LAG * (T - 1);
-    for (int tau = -2; tau <= last; tau++) {
-        // P-stage: t with 0 <= tau + 2 - 4t < Sp
-        {
-            int hi = (tau + 2) / SM_LAG;
-            if (tau + 2 < 0) hi = -1;
-            int lo_num = tau + 2 - (Sp - 1);
-            int lo = lo_num <= 0 ? 0 : (lo_num + SM_LAG - 1) / SM_LAG;
-            if (hi > T - 1) hi = T - 1;
-            if (lo <= hi) {
-                hipLaunchKernelGGL(k_psi_smooth<S>, dim3(gx, gy, hi - lo + 1), block, 0, st, a, tau, lo);
-                launches++;
-            }
+    const int last = (int)sc.launch_of_tau.size() - 1;
+    auto part = [&](int tau) {
+        StepPart p{0, 0, 0, 0, nullptr, nullptr};
+        if (tau < 0 || tau > last || sc.launch_of_tau[tau] < 0) return p;
+        const int l = sc.launch_of_tau[tau];
+        p.tau = sc.tau[l]; p.t_lo = sc.t_lo[l]; p.nt = sc.nt[l]; p.ntiles = sc.ntiles[l];
+        p.ent = sc.entries + sc.first[l];
+        p.lut = sc.lut + sc.lut_first[l];
+        return p;
+    };
+    for (int n = 0; n <= last + 2; n++) {
+        const StepPart P = part(n), W = part(n - 2);
+        if (P.ntiles + W.ntiles <= 0) continue;
+        const dim3 grid(P.ntiles + W.ntiles);
+        switch (a.C) {
+            case 1: hipLaunchKernelGGL((k_smooth_step<S, 1>), grid, block, 0, st, a, P, W); break;
+            case 2: hipLaunchKernelGGL((k_smooth_step<S, 2>), grid, block, 0, st, a, P, W); break;
+            case 3: hipLaunchKernelGGL((k_smooth_step<S, 3>), grid, block, 0, st, a, P, W); break;
+            case 4: hipLaunchKernelGGL((k_smooth_step<S, 4>), grid, block, 0, st, a, P, W); break;
+            default: throw Error("SOR kernel is instantiated for 1..4 channels");
         }
-        if (tau >= 0) {
-            int hi = tau / SM_LAG;
-            int lo_num = tau - (Sp - 1);
-            int lo = lo_num <= 0 ? 0 : (lo_num + SM_LAG - 1) / SM_LAG;
-            if (hi > T - 1) hi = T - 1;
-            if (lo <= hi) {
-                dim3 grid(gx, gy, hi - lo + 1);
-                switch (a.C) {
-                    case 1: hipLaunchKernelGGL((k_sor_smooth<S, 1>), grid, block, 0, st, a, tau, lo); break;
-                    case 2: hipLaunchKernelGGL((k_sor_smooth<S, 2>), grid, block, 0, st, a, tau, lo); break;
-                    case 3: hipLaunchKernelGGL((k_sor_smooth<S, 3>), grid, block, 0, st, a, tau, lo); break;
-                    case 4: hipLaunchKernelGGL((k_sor_smooth<S, 4>), grid, block, 0, st, a, tau, lo); break;
-                    default: throw Error("SOR kernel is instantiated for 1..4 channels");
-                }
-                launches++;
-            }
-        }
+        launches++;
     }
     return launches;
 }
-template long long launch_sor_smooth<float>(hipStream_t, const SmoothArgs<float> &);
-template long long launch_sor_smooth<double>(hipStream_t, const SmoothArgs<double> &);
+template long long launch_sor_smooth<float>(hipStream_t, const SmoothArgs<float> &, const SorSched &);
+template long long launch_sor_smooth<double>(hipStream_t, const SmoothArgs<double> &, const SorSched &);
 
 }  // namespace fr3d
