@@ -190,6 +190,13 @@ struct SorSched {
     int by = 4;                                      // tile rows the schedule was built for
     int lag = 2;                                     // hyperplanes between consecutive in-flight iterations
     std::vector<int> launch_of_tau;                  // tau -> index into the per-launch vectors, -1 = nothing to do
+    // lag-4 schedules only: the surface voxels of every hyperplane (k << 16 | j, sorted), so that the
+    // a_smooth != 1 kernels can run them in dense workgroups of their own (their ghost handling is
+    // expensive and would otherwise diverge in every row's first and last wave)
+    std::vector<int> bnd_first, bnd_count;           // per hyperplane s (host copies)
+    int *bnd_kj = nullptr;                           // device, all planes back to back
+    int *bnd_meta = nullptr;                         // device, (first, count) per hyperplane
+    int bnd_max = 0;                                 // largest bnd_count
 };
 // Tile = 64 lanes along j x `by` rows.  Measured on MI355X: 4 rows at every level size (1 and 2 rows
 // are within 2 % since the neighbour loads became unconditional); FR3D_SOR_BY overrides.

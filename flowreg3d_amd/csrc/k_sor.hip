@@ -194,6 +194,36 @@ SorSched build_sor_schedule(const Skew &sk, int T, int by, int lag)
     FR3D_HIP(hipMemcpy(sc.entries, ent.data(), ent.size() * sizeof(SorEntry), hipMemcpyHostToDevice));
     FR3D_HIP(hipMalloc((void **)&sc.lut, std::max<size_t>(lut.size(), 1) * sizeof(int)));
     FR3D_HIP(hipMemcpy(sc.lut, lut.data(), lut.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (lag != 2) {
+        FR3D_CHECK(Z <= 65535 && Y <= 65535, "a_smooth != 1 solver: axis longer than 65535");
+        std::vector<int> kj;
+        sc.bnd_first.assign(S, 0);
+        sc.bnd_count.assign(S, 0);
+        for (int s = 0; s < S; s++) {
+            sc.bnd_first[s] = (int)kj.size();
+            const int klo = std::max(0, s - (X - 1) - (Y - 1)), khi = std::min(Z - 1, s);
+            for (int k = klo; k <= khi; k++) {
+                const int r = s - k;
+                const int jlo = sk_jm(X, r), jhi = std::min(Y - 1, r);
+                for (int j = jlo; j <= jhi; j++) {
+                    const int i = r - j;
+                    if (k == 0 || k == Z - 1 || j == 0 || j == Y - 1 || i == 0 || i == X - 1) kj.push_back((k << 16) | j);
+                    else if (j < jhi - 1) j = jhi - 1;  // interior of a row: jump to its last voxels
+                }
+            }
+            sc.bnd_count[s] = (int)kj.size() - sc.bnd_first[s];
+            sc.bnd_max = std::max(sc.bnd_max, sc.bnd_count[s]);
+        }
+        FR3D_HIP(hipMalloc((void **)&sc.bnd_kj, std::max<size_t>(kj.size(), 1) * sizeof(int)));
+        FR3D_HIP(hipMemcpy(sc.bnd_kj, kj.data(), kj.size() * sizeof(int), hipMemcpyHostToDevice));
+        std::vector<int> meta(2 * (size_t)S);
+        for (int s = 0; s < S; s++) {
+            meta[2 * s] = sc.bnd_first[s];
+            meta[2 * s + 1] = sc.bnd_count[s];
+        }
+        FR3D_HIP(hipMalloc((void **)&sc.bnd_meta, meta.size() * sizeof(int)));
+        FR3D_HIP(hipMemcpy(sc.bnd_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     return sc;
 }
 
@@ -201,6 +231,10 @@ void free_sor_schedule(SorSched &s)
 {
     if (s.entries) (void)hipFree(s.entries);
     if (s.lut) (void)hipFree(s.lut);
+    if (s.bnd_kj) (void)hipFree(s.bnd_kj);
+    if (s.bnd_meta) (void)hipFree(s.bnd_meta);
+    s.bnd_kj = nullptr;
+    s.bnd_meta = nullptr;
     s.entries = nullptr;
     s.lut = nullptr;
 }

@@ -81,28 +81,22 @@ struct SmoothPos {
     int t, s, k, j, i;
     size_t c0, xm, xp, ym, yp, zm, zp;  // element offsets of the voxel and its six neighbours
 };
+// offsets of voxel (k,j) of hyperplane s; false if (k,j) is not a voxel of that plane
 template <typename S>
-__device__ __forceinline__ bool smooth_locate(const SmoothArgs<S> &a, int b, int tau, int t_lo, int nt,
-                                              const SorEntry *__restrict__ ent, const int *__restrict__ lut,
-                                              SmoothPos &p)
+__device__ __forceinline__ bool smooth_offsets(const SmoothArgs<S> &a, int s, int k, int jj_or_j, bool is_jj, SmoothPos &p)
 {
     const int Z = a.view.Z, Y = a.view.Y, X = a.view.X, Yp = a.view.Yp;
     const long long plane = a.view.plane;
-    int lo = lut[b >> SOR_LUT_SHIFT];
-    while (lo + 1 < nt && ent[lo + 1].pre <= b) lo++;
-    const SorEntry en = ent[lo];
-    const int local = b - en.pre;
-    p.t = t_lo + lo;
-    p.s = tau - SM_LAG * p.t;
-    p.k = (en.kb0 + local / en.njb) * (int)blockDim.y + threadIdx.y;
-    if (p.k >= Z) return false;
-    const int r = p.s - p.k;
+    if (k >= Z) return false;
+    const int r = s - k;
     const int jm0 = sk_jm(X, r);
-    const int jj = (local % en.njb) * 64 + threadIdx.x;
+    const int jj = is_jj ? jj_or_j : jj_or_j - jm0;
+    p.s = s;
+    p.k = k;
     p.j = jj + jm0;
     p.i = r - p.j;
     if (r < 0 || p.j >= Y || p.i < 0) return false;
-    const long long c0 = (long long)p.s * plane + (long long)p.k * Yp + jj;
+    const long long c0 = (long long)s * plane + (long long)k * Yp + jj;
     const long long d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
     p.c0 = (size_t)c0;
     p.xm = (size_t)(c0 - plane + d1);
@@ -113,14 +107,53 @@ __device__ __forceinline__ bool smooth_locate(const SmoothArgs<S> &a, int b, int
     p.zp = (size_t)(c0 + plane + Yp);
     return true;
 }
-
-// P-stage: psi_s^t on hyperplane q = tau - 4t (the caller passes tau = step + 2)
 template <typename S>
-__device__ __forceinline__ void psi_body(const SmoothArgs<S> &a, int b, int tau, int t_lo, int nt,
-                                         const SorEntry *__restrict__ ent, const int *__restrict__ lut)
+__device__ __forceinline__ bool on_surface(const SmoothArgs<S> &a, const SmoothPos &p)
 {
-    SmoothPos p;
-    if (!smooth_locate(a, b, tau, t_lo, nt, ent, lut, p)) return;
+    return p.k == 0 || p.k == a.view.Z - 1 || p.j == 0 || p.j == a.view.Y - 1 || p.i == 0 || p.i == a.view.X - 1;
+}
+
+// One part of a step: the tiles (interior voxels) or the surface-voxel workgroups of the iterations
+// t_lo .. t_lo+nt-1, iteration t working on hyperplane tau - SM_LAG*t.
+struct StepPart {
+    int tau, t_lo, nt, ntiles;
+    const SorEntry *ent;
+    const int *lut;
+};
+// interior tile `b` of a part -> voxel of this lane (false: no voxel here, or a surface voxel, which
+// belongs to the surface workgroups)
+template <typename S>
+__device__ __forceinline__ bool locate_tile(const SmoothArgs<S> &a, int b, const StepPart &P, SmoothPos &p)
+{
+    int lo = P.lut[b >> SOR_LUT_SHIFT];
+    while (lo + 1 < P.nt && P.ent[lo + 1].pre <= b) lo++;
+    const SorEntry en = P.ent[lo];
+    const int local = b - en.pre;
+    p.t = P.t_lo + lo;
+    const int k = (en.kb0 + local / en.njb) * (int)blockDim.y + threadIdx.y;
+    const int jj = (local % en.njb) * 64 + threadIdx.x;
+    if (!smooth_offsets(a, P.tau - SM_LAG * p.t, k, jj, true, p)) return false;
+    return !on_surface(a, p);
+}
+// surface workgroup `b` of a part (cb workgroups of 256 lanes per iteration) -> surface voxel of this lane
+template <typename S>
+__device__ __forceinline__ bool locate_surface(const SmoothArgs<S> &a, int b, int cb, const StepPart &P,
+                                               const int *__restrict__ meta, const int *__restrict__ kj, SmoothPos &p)
+{
+    p.t = P.t_lo + b / cb;
+    const int s = P.tau - SM_LAG * p.t;
+    if (s < 0 || s >= a.S_planes) return false;
+    const int n = (b % cb) * 256 + threadIdx.y * 64 + threadIdx.x;
+    if (n >= meta[2 * s + 1]) return false;
+    const int v = kj[meta[2 * s] + n];
+    return smooth_offsets(a, s, v >> 16, v & 0xffff, false, p);
+}
+
+// P-stage: psi_s^t of one voxel.  INTERIOR: no clamping, no ghosts -- psi_smooth_at with the six
+// neighbours at row-uniform offsets; otherwise the generic evaluation with clamped indices.
+template <typename S, bool INTERIOR>
+__device__ __forceinline__ void psi_voxel(const SmoothArgs<S> &a, const SmoothPos &p)
+{
     SmoothView<S> v = a.view;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -128,8 +161,7 @@ __device__ __forceinline__ void psi_body(const SmoothArgs<S> &a, int b, int tau,
         v.Dm2[c] = pick_buffer(a, (p.t + 1) % 3, c);  // (t-2) mod 3
     }
     double ps;
-    if (p.k > 0 && p.k < v.Z - 1 && p.j > 0 && p.j < v.Y - 1 && p.i > 0 && p.i < v.X - 1) {
-        // interior: no clamping, no ghosts -- psi_smooth_at with the six neighbours at row-uniform offsets
+    if constexpr (INTERIOR) {
         double g = 0.0;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -148,18 +180,15 @@ __device__ __forceinline__ void psi_body(const SmoothArgs<S> &a, int b, int tau,
         if (sizeof(S) == 4) ps = v.a_smooth * (double)powf((float)(g + 1e-5), (float)(v.a_smooth - 1.0));
         else ps = v.a_smooth * pow(g + 1e-5, v.a_smooth - 1.0);
     } else {
-        ps = psi_smooth_at(v, p.k, p.j, p.i);  // surface voxel: clamped indices and ghost values
+        ps = psi_smooth_at(v, p.k, p.j, p.i);  // clamped indices and ghost values
     }
     a.Ps[p.c0] = (S)ps;
 }
 
 // sweep: iteration t on hyperplane s = tau - 4t
-template <typename S, int C>
-__device__ __forceinline__ void sweep_body(const SmoothArgs<S> &a, int b, int tau, int t_lo, int nt,
-                                           const SorEntry *__restrict__ ent, const int *__restrict__ lut)
+template <typename S, int C, bool INTERIOR>
+__device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const SmoothPos &p)
 {
-    SmoothPos p;
-    if (!smooth_locate(a, b, tau, t_lo, nt, ent, lut, p)) return;
     const int Z = a.view.Z, Y = a.view.Y, X = a.view.X;
     const int t = p.t, k = p.k, j = p.j, i = p.i;
     SmoothView<S> v = a.view;
@@ -182,7 +211,8 @@ __device__ __forceinline__ void sweep_body(const SmoothArgs<S> &a, int b, int ta
     const int nj[6] = {j, j, j - 1, j + 1, j, j};
     const int ni[6] = {i, i, i, i, i - 1, i + 1};
     const size_t off[6] = {p.zm, p.zp, p.ym, p.yp, p.xm, p.xp};
-    const bool inside[6] = {k > 0, k < Z - 1, j > 0, j < Y - 1, i > 0, i < X - 1};
+    const bool inside[6] = {INTERIOR || k > 0, INTERIOR || k < Z - 1, INTERIOR || j > 0,
+                            INTERIOR || j < Y - 1, INTERIOR || i > 0, INTERIOR || i < X - 1};
     const double sc[6] = {a.az, a.az, a.ay, a.ay, a.ax, a.ax};
     const bool newer[6] = {true, false, true, false, true, false};  // minus side already swept
     // psi_s and the neighbour terms.  Inside the volume: loads at the neighbour's offset (a ghost
@@ -276,31 +306,45 @@ __device__ __forceinline__ void sweep_body(const SmoothArgs<S> &a, int b, int ta
     Dn[2][c0] = (S)dw1;
 }
 
-// One launch per step: the first `ntP` workgroups are P-stage tiles (psi_s^t on plane n - 4t), the rest
-// sweep tiles (iteration t on plane n - 2 - 4t).  Within a step the two are independent: the sweep
-// reads psi_s of planes finished in earlier steps, the P-stage reads increments swept in earlier steps.
-struct StepPart {
-    int tau, t_lo, nt, ntiles;
-    const SorEntry *ent;
-    const int *lut;
-};
+// One launch per step n, four kinds of workgroups: P-stage tiles (psi_s^t on plane n - 4t, interior
+// voxels), sweep tiles (iteration t on plane n - 2 - 4t, interior voxels), and for each of the two the
+// surface voxels of the same planes packed 256 to a workgroup.  Within a step all four are independent:
+// the sweep reads psi_s of planes finished in earlier steps, the P-stage increments swept in earlier steps.
 template <typename S, int C>
 __global__ void __launch_bounds__(256)
-k_smooth_step(const SmoothArgs<S> a, StepPart P, StepPart W)
+k_smooth_step(const SmoothArgs<S> a, StepPart P, StepPart W, int cb, const int *__restrict__ meta,
+              const int *__restrict__ kj)
 {
-    const int b = blockIdx.x;
-    if (b < P.ntiles) psi_body<S>(a, b, P.tau, P.t_lo, P.nt, P.ent, P.lut);
-    else sweep_body<S, C>(a, b - P.ntiles, W.tau, W.t_lo, W.nt, W.ent, W.lut);
+    int b = blockIdx.x;
+    SmoothPos p;
+    if (b < P.ntiles) {
+        if (locate_tile(a, b, P, p)) psi_voxel<S, true>(a, p);
+        return;
+    }
+    b -= P.ntiles;
+    if (b < W.ntiles) {
+        if (locate_tile(a, b, W, p)) sweep_voxel<S, C, true>(a, p);
+        return;
+    }
+    b -= W.ntiles;
+    if (b < P.nt * cb) {
+        if (locate_surface(a, b, cb, P, meta, kj, p)) psi_voxel<S, false>(a, p);
+        return;
+    }
+    b -= P.nt * cb;
+    if (locate_surface(a, b, cb, W, meta, kj, p)) sweep_voxel<S, C, false>(a, p);
 }
 
-// One schedule (SM_LAG planes between iterations) serves both parts: step n runs the P-stage with
+// One schedule (SM_LAG planes between iterations) serves both stages: step n runs the P-stage with
 // tau = n and the sweep with tau = n - 2, i.e. psi_s^t is two planes ahead of sweep t.
 template <typename S>
 long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSched &sc)
 {
     if (a.iterations <= 0) return 0;
-    FR3D_CHECK(sc.lag == SM_LAG, "internal: smooth solver needs the lag-4 schedule");
+    FR3D_CHECK(sc.lag == SM_LAG && sc.bnd_kj && sc.bnd_meta, "internal: smooth solver needs the lag-4 schedule");
     const dim3 block(64, sc.by);
+    FR3D_CHECK(sc.by == 4, "internal: smooth solver workgroups are 64 x 4");
+    const int cb = cdiv(std::max(sc.bnd_max, 1), 256);
     long long launches = 0;
     const int last = (int)sc.launch_of_tau.size() - 1;
     auto part = [&](int tau) {
@@ -314,13 +358,14 @@ long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSch
     };
     for (int n = 0; n <= last + 2; n++) {
         const StepPart P = part(n), W = part(n - 2);
-        if (P.ntiles + W.ntiles <= 0) continue;
-        const dim3 grid(P.ntiles + W.ntiles);
+        const int blocks = P.ntiles + W.ntiles + (P.nt + W.nt) * cb;
+        if (blocks <= 0) continue;
+        const dim3 grid(blocks);
         switch (a.C) {
-            case 1: hipLaunchKernelGGL((k_smooth_step<S, 1>), grid, block, 0, st, a, P, W); break;
-            case 2: hipLaunchKernelGGL((k_smooth_step<S, 2>), grid, block, 0, st, a, P, W); break;
-            case 3: hipLaunchKernelGGL((k_smooth_step<S, 3>), grid, block, 0, st, a, P, W); break;
-            case 4: hipLaunchKernelGGL((k_smooth_step<S, 4>), grid, block, 0, st, a, P, W); break;
+            case 1: hipLaunchKernelGGL((k_smooth_step<S, 1>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
+            case 2: hipLaunchKernelGGL((k_smooth_step<S, 2>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
+            case 3: hipLaunchKernelGGL((k_smooth_step<S, 3>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
+            case 4: hipLaunchKernelGGL((k_smooth_step<S, 4>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
             default: throw Error("SOR kernel is instantiated for 1..4 channels");
         }
         launches++;
