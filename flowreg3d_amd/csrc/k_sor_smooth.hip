@@ -10,11 +10,14 @@
 //    of iteration t-2 (set_boundary_3d ran before sweep t-1, :379-381).  Both states must survive
 //    while iteration t runs, so the increments are triple-buffered (D[t%3]) and the in-flight
 //    iterations are 4 hyperplanes apart instead of 2:
-//        step tau:  P-stage  psi_s^t(plane q)   for q = tau + 2 - 4t   (needs D[(t-1)%3] on q-1..q+1)
-//                   sweep    iteration t, plane s = tau - 4t           (needs psi_s^t on s-1..s+1)
-//    psi_s at ghost positions (needed by surface voxels) is evaluated on the fly from the same
-//    two buffers.  S + 4(T-1) + 2 steps per level, two launches per step; this path favours
-//    fidelity over speed (it is not on any BASELINE configuration: OFOptions.a_smooth = 1.0).
+//        step n:  P-stage  psi_s^t(plane n - 4t)      (needs D[(t-1)%3] on the planes next to it)
+//                 sweep    iteration t, plane n - 2 - 4t  (needs psi_s^t on the planes next to it)
+//    psi_s at ghost positions (needed by surface voxels) is evaluated on the fly from the same two
+//    buffers.  One launch per step on the lag-4 tile schedule of k_sor.hip: P-stage tiles, sweep tiles
+//    and -- packed into dense workgroups of their own, because their ghost handling is expensive and
+//    would otherwise diverge in the first and last wave of every row -- the surface voxels of both.
+//    fp64 arithmetic (the (u + du) - u differences cancel in fp32); not on any BASELINE configuration
+//    (OFOptions.a_smooth = 1.0), but get_displacement's own default.
 #include <cstdlib>
 
 #include "fr3d_internal.h"
