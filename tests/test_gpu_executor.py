@@ -137,3 +137,28 @@ def test_concurrent_callers_are_serialised_correctly(hip, oracle):
     for a, b in zip(serial, threaded):
         assert np.array_equal(a, b)
     assert not np.array_equal(serial[0], serial[5])
+
+
+def test_errors_surface_as_exceptions_and_leave_the_engine_usable(hip):
+    """A failing progress callback is re-raised after the batch, bad flow parameters are refused by the
+    engine, and the executor keeps working afterwards (no lock or worker thread left behind)."""
+    from flowreg3d_amd.executor import HipExecutor3D
+    fixed, batch = _series(T=5, shape=(10, 14, 16))
+    w0 = np.zeros(batch.shape[1:4] + (3,), np.float32)
+    fp = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=5, min_level=0, levels=2, eta=0.8,
+              a_smooth=1.0, a_data=0.45)
+
+    def boom(n):
+        raise KeyError("callback failed")
+
+    with HipExecutor3D() as ex:
+        with pytest.raises(KeyError):
+            ex.process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=fp, progress_callback=boom)
+        with pytest.raises((ValueError, RuntimeError)):
+            ex.process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=dict(fp, eta=1.5))
+        with pytest.raises(NotImplementedError):
+            ex.process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=dict(fp, cc_initialization=True))
+        with pytest.raises(ValueError):
+            ex.process_batch(batch, batch[:, :-1], fixed, fixed, w0, None, None, flow_params=fp)
+        reg, flows = ex.process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=fp)
+    assert np.isfinite(flows).all() and reg.shape == batch.shape
