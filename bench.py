@@ -227,6 +227,8 @@ def main():
         # steps): the practical ceiling behind the nominal 8 TB/s
         stream = C.c_double(0.0)
         _lib.check(lib.fr3d_stream_probe(1 << 28, 20, C.byref(stream)))
+        rstream = C.c_double(0.0)  # read-only stream (the sweep's real traffic is 83 % reads)
+        _lib.check(lib.fr3d_read_probe(1 << 26, 20, C.byref(rstream)))
         out = {
             "metric": "volumes/sec (3D flow solve + warp)",
             "value": (K * world) / elapsed,
@@ -253,6 +255,7 @@ def main():
                          "avg_launch_us": 1e3 * sor["ms"] / max(sor["launches"], 1),
                          "launches": sor["launches"],
                          "stream_measured": round(stream.value, 1),
+                         "read_stream_measured": round(rstream.value, 1),
                          "frac_of_stream_measured": round(achieved / stream.value, 4) if stream.value > 0 else None},
             "kernel_ms_per_step": {k: round(v["ms"] / K, 3) for k, v in stats.items()},
             # the other stages of the path against the same HBM roofline, algorithmic bytes as in

@@ -1443,6 +1443,28 @@ int fr3d_stream_probe(size_t n_floats, int reps, double *gbytes_per_s)
     *gbytes_per_s = 12.0 * (double)n_floats * reps / ((double)ms * 1e-3) / 1e9;
     FR3D_CATCH
 }
+int fr3d_read_probe(size_t n_floats, int reps, double *gbytes_per_s)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(n_floats > 0 && reps > 0 && gbytes_per_s, "bad read_probe arguments");
+    Engine &e = g_eng;
+    Staged s;
+    float *x = (float *)s.alloc(n_floats * 8 * 4), *sink = (float *)s.alloc(64 * 4);
+    FR3D_HIP(hipMemsetAsync(x, 0, n_floats * 8 * 4, e.st));
+    launch_read8(e.st, x, (long long)n_floats, sink);  // first touch outside the timed part
+    hipEvent_t a = e.get_event(), b = e.get_event();
+    FR3D_HIP(hipEventRecord(a, e.st));
+    for (int r = 0; r < reps; r++) launch_read8(e.st, x, (long long)n_floats, sink);
+    FR3D_HIP(hipEventRecord(b, e.st));
+    FR3D_HIP(hipEventSynchronize(b));
+    float ms = 0.0f;
+    FR3D_HIP(hipEventElapsedTime(&ms, a, b));
+    e.ev_pool.push_back(a);
+    e.ev_pool.push_back(b);
+    *gbytes_per_s = 32.0 * (double)n_floats * reps / ((double)ms * 1e-3) / 1e9;
+    FR3D_CATCH
+}
 int fr3d_prof_get(fr3d_kernel_stat *out)
 {
     FR3D_TRY

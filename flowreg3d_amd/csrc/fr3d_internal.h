@@ -225,6 +225,8 @@ void launch_flow_stats(hipStream_t st, const float *flow, int Z, int Y, int X, i
 // K9 pointwise helpers
 void launch_axpy(hipStream_t st, float *y, const float *x, long long n);  // y += x
 void launch_fill(hipStream_t st, float *y, float v, long long n);
+// eight read-only streams of n floats each starting at x (measurement aid)
+void launch_read8(hipStream_t st, const float *x, long long n, float *sink);
 // interleave/deinterleave between (n,C) channels-last and planar (C,n)
 void launch_pack(hipStream_t st, const float *planar, int C, long long n, float *interleaved);
 void launch_unpack(hipStream_t st, const float *interleaved, int C, long long n, float *planar);

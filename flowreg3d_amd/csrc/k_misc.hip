@@ -9,6 +9,22 @@ __global__ void __launch_bounds__(256) k_axpy(float *__restrict__ y, const float
     if (t < n) y[t] = y[t] + x[t];
 }
 
+// read-only stream for fr3d_stream_probe: every thread sums one element of each of eight streams (the
+// SOR sweep is read-heavy, 95 of its 115 real bytes per update are reads); one store per wave
+__global__ void __launch_bounds__(256) k_read8(const float *__restrict__ x, long long n, float *__restrict__ sink)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float a = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) a += x[(size_t)q * n + t];
+    if (a == 123456.789f) sink[t & 63] = a;  // never true for the zero-filled probe buffer; keeps the loads alive
+}
+void launch_read8(hipStream_t st, const float *x, long long n, float *sink)
+{
+    if (n > 0) hipLaunchKernelGGL(k_read8, dim3(cdiv(n, 256)), dim3(256), 0, st, x, n, sink);
+}
+
 __global__ void __launch_bounds__(256) k_fill(float *__restrict__ y, float v, long long n)
 {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -197,6 +197,9 @@ int fr3d_prof_get(fr3d_kernel_stat *out /* FR3D_K_COUNT entries */);
  * n_floats (12 B per element: two reads, one write), HIP-event timed on the engine stream.  The
  * practical ceiling next to the nominal 8 TB/s when reading roofline fractions. */
 int fr3d_stream_probe(size_t n_floats, int reps, double *gbytes_per_s);
+/* Same for a read-only stream (eight arrays of n_floats summed per thread, 32 B per element): the
+ * ceiling for a read-heavy kernel such as the SOR sweep. */
+int fr3d_read_probe(size_t n_floats, int reps, double *gbytes_per_s);
 
 #ifdef __cplusplus
 }

@@ -120,3 +120,6 @@ def test_stream_probe_reports_a_plausible_rate(hip):
     _lib.check(lib.fr3d_stream_probe(1 << 26, 5, C.byref(rate)))
     assert 500.0 < rate.value < 8000.0, rate.value  # GB/s: below the nominal HBM peak, far above PCIe
     assert lib.fr3d_stream_probe(0, 5, C.byref(rate)) != 0
+    read = C.c_double(0.0)
+    _lib.check(lib.fr3d_read_probe(1 << 24, 5, C.byref(read)))
+    assert 500.0 < read.value < 8000.0, read.value
