@@ -98,8 +98,9 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=80, help="edge of the CPU-baseline cube")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solver-fp64", type=int, default=0, choices=(0, 1, 2),
-                    help="0 fp32 storage+update (default), 1 fp64 update arithmetic, 2 fp64 storage (parity-grade)")
+    ap.add_argument("--solver-fp64", type=int, default=1, choices=(0, 1, 2),
+                    help="0 fp32 storage+update, 1 fp32 storage with fp64 update arithmetic (default = the library's "
+                         "choice for one channel; same speed as 0), 2 fp64 storage (parity-grade, 2x the bytes)")
     ap.add_argument("--batch", type=int, default=0,
                     help="volumes solved in lock step per GPU (shared launches); 0 = 8, or 4 at 512^3 "
                          "where 8 slabs of solver operands (43 GB each) would not fit in 288 GB")
@@ -244,6 +245,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}; iterations=100, update_lag=5, eta=0.8, "
                                    "alpha=0.25, a_data=0.45, a_smooth=1; lexicographic-exact SOR",
+                       "solver": ("fp32 storage, fp32 update arithmetic", "fp32 storage, fp64 update arithmetic",
+                                  "fp64 storage and arithmetic")[args.solver_fp64],
                        "volumes_per_gpu_per_step": 1, "lockstep_batch": batch_vols,
                        "untimed_conditioning_s": args.condition if W > 0 else 0.0,
                        "sharding": f"volume-per-GPU x{world}",

@@ -583,10 +583,11 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
     }
 }
 
-// FR3D_SOLVER_AUTO: single-channel problems are well conditioned in fp32 (EPE vs the CPU path 1e-5);
-// with several channels the reference iteration itself amplifies rounding and
-// only fp64 solver storage stays below the 1e-4 bound
-static int solver_mode(const fr3d_params &p, int C) { return p.solver_fp64 < 0 ? (C >= 2 ? 2 : 0) : p.solver_fp64; }
+// FR3D_SOLVER_AUTO: one channel -> fp32 storage with fp64 update arithmetic (the sweep is memory-bound,
+// so the wider arithmetic is free, and it removes a quarter of the rounding error); several channels ->
+// fp64 storage, because the reference iteration itself amplifies rounding there
+// and only that stays below the 1e-4 bound
+static int solver_mode(const fr3d_params &p, int C) { return p.solver_fp64 < 0 ? (C >= 2 ? 2 : 1) : p.solver_fp64; }
 
 static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std::vector<Level> &lv, int min_level,
                                   const RefPyramid &rp, int nb, const float *const *moving, int Z, int Y, int X,

@@ -48,7 +48,7 @@ class Options:
     channel_normalization: str = "together"
     interpolation_method: str = "cubic"
     update_initialization_w: bool = True
-    solver_fp64: Optional[int] = None  # extension: None = fp32 solver storage for one channel, fp64 for several
+    solver_fp64: Optional[int] = None  # extension: None = fp32 solver storage (fp64 update arithmetic) for one channel, fp64 storage for several
 
     @property
     def effective_min_level(self) -> int:

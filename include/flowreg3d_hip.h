@@ -52,7 +52,7 @@ typedef struct fr3d_params {
                                           2: fp64 storage and arithmetic in the solver (2x the
                                              bytes; for configurations where the reference's own
                                              iteration is ill-conditioned);
-                                          FR3D_SOLVER_AUTO (-1): 0 for one channel, 2 for several
+                                          FR3D_SOLVER_AUTO (-1): 1 for one channel, 2 for several
                                              (what the Python mirror passes by default) */
     int reserved[7];
 } fr3d_params;

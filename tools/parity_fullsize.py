@@ -10,7 +10,7 @@ from oracle import oracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 fixed, moving, gt = fast_pair((n, n, n))
 kw = dict(alpha=(0.25,) * 3, update_lag=5, iterations=100, min_level=0, levels=4, eta=0.8, a_smooth=1.0, a_data=0.45)
-t0 = time.time(); got = fr.get_displacement(fixed, moving, **kw); t_gpu = time.time() - t0
+t0 = time.time(); got = fr.get_displacement(fixed, moving, solver_fp64=0, **kw); t_gpu = time.time() - t0
 got64 = fr.get_displacement(fixed, moving, solver_fp64=2, **kw)
 got1 = fr.get_displacement(fixed, moving, solver_fp64=1, **kw)  # fp64 arithmetic, fp32 storage
 print("gpu done %.2f s; running the oracle ..." % t_gpu, flush=True)
