@@ -36,3 +36,11 @@ def test_random_stage_inputs_match_the_oracle(hip, oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_stages
     assert fuzz_stages.run(n_cases=40, seed=5, verbose=False) == 0
+
+
+def test_random_preprocessing_inputs_match_the_oracle(hip, oracle):
+    """normalize + Gaussian filter on the device for random dtypes (u8/u16/i16/f32/f64), shapes with
+    and without a time axis, per-channel sigmas and both normalisation modes."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_preprocess
+    assert fuzz_preprocess.run(n_cases=40, seed=3, verbose=False) == 0
