@@ -614,11 +614,22 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
     if (want < 1) want = 1;
     const Level &F = lv.back();
     const Skew sk = make_skew(F.z, F.y, F.x);
-    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0);
+    const double nfin = (double)F.z * F.y * F.x;
+    // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
+    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0) + nfin * 4.0 * 9.0;
+    // volume-independent scratch of the finest level: tensor/Laplacian staging (15), moving level and
+    // its warp (2C), fp64 spline coefficients on the padded grid (~2.5), increments and flow (9),
+    // reference and weight pyramids (~4C)
+    const double scratch = nfin * 4.0 * (15.0 + 2.0 * C + 2.5 + 9.0 + 4.0 * C) * (g_fp64_storage ? 1.5 : 1.0);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        // buffers already held by the engine are reused, so this is conservative
-        const double budget = 0.85 * (double)total_b;
+        // what the solver slabs may occupy: the memory that is free now plus what the engine already
+        // holds (its buffers are reused), minus a margin for the per-level scratch; never more than
+        // 85 % of the device.  Memory the caller holds (a resident series, torch tensors) is respected.
+        size_t held = 0;
+        for (const auto &kv : g_eng.bufs) held += kv.second.cap;
+        const double avail = (double)free_b + (double)held - scratch - 2.0 * 1073741824.0;
+        const double budget = std::min(0.85 * (double)total_b, avail);
         while (want > 1 && per_vol * want > budget) want--;
     }
     return want;
