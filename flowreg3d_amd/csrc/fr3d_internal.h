@@ -97,6 +97,7 @@ struct SorArgsT {
     int nvol;
     long long vsM, vsA, vsL, vsD;
     int dbg;  // measurement-only ablation bits (FR3D_SOR_DBG); 0 in production
+    int t_base;  // iteration number of the schedule's iteration 0 (windowed sweeps, see launch_sor)
 };
 using SorArgs = SorArgsT<float>;
 

@@ -84,7 +84,7 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
     const R su_z = (R)ldb(dU, zm) + (R)ldb(dU, zp), sv_z = (R)ldb(dV, zm) + (R)ldb(dV, zp),
             sw_z = (R)ldb(dW, zm) + (R)ldb(dW, zp);
     R m[9];
-    const bool upd = (t % a.update_lag) == 0 && !(a.dbg & 4);
+    const bool upd = ((a.t_base + t) % a.update_lag) == 0 && !(a.dbg & 4);
     sor_system<R, S, C, I>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
     R du1, dv1, dw1;
     sor_relax<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,

@@ -129,3 +129,24 @@ def epe(a, b, crop=0):
         a, b = a[s], b[s]
     d = np.linalg.norm(a - b, axis=-1)
     return float(d.mean()), float(d.max())
+
+
+# OFOptions solver defaults (motion_correction/OF_options_3D.py:155-174), the parameters every BASELINE
+# configuration is quoted with
+SOLVER_DEFAULTS = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=100, min_level=0, eta=0.8,
+                       a_smooth=1.0, a_data=0.45)
+
+
+def fullsize_case(name):
+    """Deterministic full-size inputs of BASELINE configs 2, 3 and 5 (the cases whose CPU-path flows
+    are sampled in tests/golden/fullsize_*.npz): -> fixed, moving, flow_gt, get_displacement kwargs."""
+    if name == "cfg2":
+        fixed, moving, gt = fast_pair((256, 256, 256))
+        return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=4)
+    if name == "cfg3":
+        fixed, moving, gt = fast_pair((512, 512, 512))
+        return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=5)
+    if name == "cfg5":
+        fixed, moving, gt = make_pair((256, 512, 512), seed=1234, channels=2, motion="expansion", cheap=True)
+        return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=8, weight=np.array([0.5, 0.5]))
+    raise ValueError(name)

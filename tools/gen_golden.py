@@ -204,6 +204,101 @@ def main():
         out["filt5_u16"] = im3d.apply_gaussian_filter(nu, np.array([1.0, 1.0, 1.0, 0.1]), mode="reflect", truncate=4.0)
         save("f1_preproc", **out)
 
+    # ---- the executor boundary: the reference's own SequentialExecutor3D.process_batch ------------
+    # (motion_correction/parallelization/sequential_3d.py:37-175) with the reference's
+    # get_displacement / imregister_wrapper injected, exactly as BatchMotionCorrector calls it
+    # (compensate_recording_3D.py:301-340); the flow_params dict has the pipeline's keys.
+    if want("ex_seq"):
+        from flowreg3d.motion_correction.parallelization.sequential_3d import SequentialExecutor3D
+        from scipy.ndimage import gaussian_filter
+        out = {}
+
+        def series(shape, C, T, seed):
+            """raw series (T,Z,Y,X,C) float64 in camera-like counts + its fixed reference"""
+            ref = np.stack([smooth_volume(shape, seed + c, sigma=2.0) for c in range(C)], -1)
+            vols = []
+            for t in range(T):
+                sh = (0.9 * np.cos(0.9 * t), -0.6 + 0.2 * t, 0.4 * np.sin(1.3 * t + 0.5))
+                vols.append(np.stack([moved(ref[..., c], sh, 0) for c in range(C)], -1))
+            raw = np.stack(vols, 0).astype(np.float64) * 3000.0 + 200.0
+            return raw, ref.astype(np.float64) * 3000.0 + 200.0
+
+        def proc_of(a, lo, hi):
+            # what the pipeline feeds as batch_proc: normalised to the reference's range, float64
+            return (a - lo) / (hi - lo + 1e-8)
+
+        ex = SequentialExecutor3D(n_workers=1)
+        cases = {
+            "c1_f32": dict(shape=(12, 18, 18), C=1, T=3, dtype=np.float32, method="cubic",
+                           fp=dict(alpha=(0.25, 0.25, 0.25), weight=np.array([1.0]), levels=50, min_level=0, eta=0.8,
+                                   update_lag=5, iterations=20, a_smooth=1.0, a_data=0.45)),
+            "c2_u16": dict(shape=(12, 16, 20), C=2, T=2, dtype=np.uint16, method="cubic",
+                           fp=dict(alpha=(0.3, 0.25, 0.2), weight=np.array([0.6, 0.4]), levels=50, min_level=0, eta=0.8,
+                                   update_lag=5, iterations=15, a_smooth=1.0, a_data=0.45)),
+            "c1_f64_lin": dict(shape=(10, 14, 16), C=1, T=2, dtype=np.float64, method="linear",
+                               fp=dict(alpha=(0.25, 0.25, 0.25), weight=np.array([1.0]), levels=50, min_level=1, eta=0.8,
+                                       update_lag=4, iterations=12, a_smooth=1.0, a_data=0.45)),
+        }
+        names = []
+        for name, cs in cases.items():
+            t0 = time.time()
+            raw64, ref_raw = series(cs["shape"], cs["C"], cs["T"], 300 + len(names) * 10)
+            batch = raw64.astype(cs["dtype"])            # integer dtypes truncate like a camera would deliver
+            lo, hi = ref_raw.min(), ref_raw.max()
+            batch_proc = proc_of(batch.astype(np.float64), lo, hi)
+            ref_proc = proc_of(ref_raw, lo, hi)
+            rng = np.random.Generator(np.random.PCG64(55))
+            w_init = np.stack([gaussian_filter(0.4 * (rng.random(cs["shape"]) - 0.5), 2.0) for _ in range(3)], -1)
+            w_init = w_init.astype(np.float32)
+            calls = []
+            reg, flows = ex.process_batch(batch, batch_proc, ref_raw, ref_proc, w_init, of.get_displacement,
+                                          of.imregister_wrapper, interpolation_method=cs["method"],
+                                          progress_callback=lambda n: calls.append(n), flow_params=dict(cs["fp"]))
+            assert reg.dtype == batch.dtype and flows.dtype == np.float32 and sum(calls) == cs["T"]
+            fp = cs["fp"]
+            out[f"{name}_batch"] = batch
+            out[f"{name}_batch_proc"] = batch_proc
+            out[f"{name}_ref_raw"] = ref_raw
+            out[f"{name}_ref_proc"] = ref_proc
+            out[f"{name}_w_init"] = w_init
+            out[f"{name}_registered"] = reg
+            out[f"{name}_flows"] = flows
+            out[f"{name}_weight"] = np.asarray(fp["weight"], np.float64)
+            out[f"{name}_params"] = np.array([fp["alpha"][0], fp["alpha"][1], fp["alpha"][2], fp["update_lag"],
+                                              fp["iterations"], fp["min_level"], fp["levels"], fp["eta"],
+                                              fp["a_smooth"], fp["a_data"], 3 if cs["method"] == "cubic" else 1],
+                                             dtype=np.float64)
+            names.append(name)
+            print(f"    ex_seq/{name}: {time.time() - t0:.1f}s, registered {reg.dtype}, mean flow {flows.mean(axis=(0, 1, 2, 3))}")
+        out["cases"] = np.array(names)
+        save("ex_seq", **out)
+
+    # ---- f-4: update_reference arithmetic (compensate_recording_3D.py:395-429): per channel, warp the
+    # last <= 100 batch_proc volumes by their flows (imregister_wrapper, fp32 result), mean over them in fp64
+    if want("f4_update_ref"):
+        from scipy.ndimage import gaussian_filter
+        shape, C, T = (10, 14, 12), 2, 5
+        rng = np.random.Generator(np.random.PCG64(91))
+        bp = np.stack([np.stack([smooth_volume(shape, 500 + 7 * t + c, 1.5) for c in range(C)], -1) for t in range(T)],
+                      0).astype(np.float64)
+        ref_proc = np.stack([smooth_volume(shape, 490 + c, 1.5) for c in range(C)], -1).astype(np.float64)
+        w = np.stack([np.stack([gaussian_filter(5.0 * (rng.random(shape) - 0.5), 1.5) for _ in range(3)], -1)
+                      for t in range(T)], 0).astype(np.float32)
+        res = {}
+        for method in ("cubic", "linear"):
+            new_ref = np.zeros_like(ref_proc)
+            n_ref = min(100, T)
+            start = T - n_ref
+            for c in range(C):
+                comp = np.zeros((n_ref,) + shape, dtype=np.float64)
+                for t in range(n_ref):
+                    comp[t] = of.imregister_wrapper(bp[start + t, ..., c], w[start + t, ..., 0], w[start + t, ..., 1],
+                                                    w[start + t, ..., 2], ref_proc[..., c], interpolation_method=method)
+                new_ref[..., c] = np.mean(comp, axis=0)
+            res[method] = new_ref
+        save("f4_update_ref", batch_proc=bp, ref_proc=ref_proc, w=w, new_ref_cubic=res["cubic"],
+             new_ref_linear=res["linear"])
+
     # ---- end to end --------------------------------------------------------------------------
     def e2e(name, shape, C, shift, kw, uvw_amp=0.0, weight=None):
         t0 = time.time()
