@@ -71,10 +71,18 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, _vp, _vp, PROGRESS_FN, _vp]),
     "fr3d_process_batch_dev": (C.c_int, [C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, _vp, _vp, PROGRESS_FN, _vp]),
+    "fr3d_process_batch_raw": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, PROGRESS_FN, _vp]),
+    "fr3d_process_batch_raw_dev": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, PROGRESS_FN, _vp]),
     "fr3d_preprocess": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double,
                                   _vp, C.c_int]),
     "fr3d_preprocess_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_double, _vp, C.c_int]),
+    "fr3d_update_reference": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, _dp]),
+    "fr3d_update_reference_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, _dp]),
     "fr3d_flow_stats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "fr3d_flow_stats_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "fr3d_resize3d": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

@@ -218,6 +218,14 @@ struct Engine {
     std::map<std::string, DevBuf> bufs;
     std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
     std::map<std::tuple<int, int, int, int, int>, SorSched> scheds;  // (Z,Y,X,iterations,lag) of a level
+    // pair-sweep schedules (k_sor_pair.hip): keyed (Z,Y,X,iterations,-rows)
+    const SorSched &pair_sched(const Skew &sk, int iterations, int rows)
+    {
+        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, -rows);
+        auto it = scheds.find(key);
+        if (it == scheds.end()) it = scheds.emplace(key, build_sor_pair_schedule(sk, iterations, rows)).first;
+        return it->second;
+    }
 
     const SorSched &sched(const Skew &sk, int iterations, int lag = 2)
     {
@@ -331,10 +339,10 @@ static void resize3d(Engine &e, const float *src, int cs, int co, int D, int H, 
 }
 
 // cubic warp of one channel
-template <typename TV, typename TF>
+template <typename TV, typename TF, typename TR = TV, typename TO = float>
 static void warp_cubic_chan(Engine &e, const TV *vol, int vcs, int vco, const TF *pu, const TF *pv,
-                            const TF *pw, int fs, double hx, double hy, double hz, const TV *ref,
-                            int Z, int Y, int X, float *out, int ocs, int oco)
+                            const TF *pw, int fs, double hx, double hy, double hz, const TR *ref,
+                            int Z, int Y, int X, TO *out, int ocs, int oco)
 {
     const int npad = 12;
     const size_t np = (size_t)(Z + 2 * npad) * (Y + 2 * npad) * (X + 2 * npad);
@@ -346,8 +354,8 @@ static void warp_cubic_chan(Engine &e, const TV *vol, int vcs, int vco, const TF
     }
     {
         Span sp(e, FR3D_K_WARP, 24.0 * (double)Z * Y * X, 1, (long long)Z * Y * X);
-        launch_warp_cubic<TF, TV>(e.st, coef, npad, pu, pv, pw, fs, hx, hy, hz, ref, vcs, vco, Z, Y, X,
-                                  out, ocs, oco);
+        launch_warp_cubic<TF, TR, TO>(e.st, coef, npad, pu, pv, pw, fs, hx, hy, hz, ref, vcs, vco, Z, Y, X,
+                                      out, ocs, oco);
     }
 }
 
@@ -500,9 +508,18 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         }
         a.iterations = p.iterations;
         a.update_lag = p.update_lag;
+        S *dres = dbuf;  // where the increments end up
         if (p.a_smooth == 1.0) {
+            const int pair_rows = sor_kernel_choice(sk);
+            if (pair_rows) {  // two hyperplanes per launch: increments double-buffered by iteration parity
+                S *dbuf2 = (S *)e.bufs["d2_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
+                FR3D_HIP(hipMemsetAsync(dbuf2, 0, ns * 3 * nb * sizeof(S), e.st));
+                for (int d = 0; d < 3; d++) a.dB[d] = dbuf2 + (size_t)d * ns;
+                if (sor_pair_result(p.iterations)) dres = dbuf2;
+            }
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
-            long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
+            long long n = pair_rows ? launch_sor_pair<S>(e.st, a, p.solver_fp64 != 0, e.pair_sched(sk, p.iterations, pair_rows))
+                                    : launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
             sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
         } else {
             // a_smooth != 1 (k_sor_smooth.hip): psi_smooth every iteration, triple-buffered increments,
@@ -552,7 +569,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 Span sp(e, FR3D_K_OTHER, 0, 0, 0);
                 // increments leave the solver rounded to fp32: the next level (and the executor) cast to
                 // fp32 anyway (util/resize_util_3D.py:116, sequential_3d.py:150) and the median commutes with it
-                launch_unskew_copy_n<S, float>(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
+                launch_unskew_copy_n<S, float>(e.st, dres + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
             }
             if (med) {
                 Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);
@@ -606,17 +623,23 @@ static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std:
 static int g_batch_hint = 0;  // fr3d_set_batch()
 static bool g_fp64_storage = false;
 
-static int pick_batch(int T, const std::vector<Level> &lv, int C)
+// fr3d_set_batch(), else FR3D_BATCH, else 4
+static int batch_wanted()
 {
     static const char *env = getenv("FR3D_BATCH");
-    int want = g_batch_hint > 0 ? g_batch_hint : (env ? std::max(1, atoi(env)) : 4);
+    return g_batch_hint > 0 ? g_batch_hint : (env ? std::max(1, atoi(env)) : 4);
+}
+
+static int pick_batch(int T, const std::vector<Level> &lv, int C)
+{
+    int want = batch_wanted();
     if (want > T) want = T;
     if (want < 1) want = 1;
     const Level &F = lv.back();
     const Skew sk = make_skew(F.z, F.y, F.x);
     const double nfin = (double)F.z * F.y * F.x;
-    // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
-    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0) + nfin * 4.0 * 9.0;
+    // skewed solver slabs (factors, system, L, two increment buffers) + the level flows of a volume (two generations of u,v,w)
+    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 9.0) + nfin * 4.0 * 9.0;
     // volume-independent scratch of the finest level: tensor/Laplacian staging (15), moving level and
     // its warp (2C), fp64 spline coefficients on the padded grid (~2.5), increments and flow (9),
     // reference and weight pyramids (~4C)
@@ -661,20 +684,45 @@ static void get_displacement_dev(const fr3d_params *p, const float *fixed, const
     FR3D_HIP(hipStreamSynchronize(e.st));
 }
 
-template <typename TV, typename TF>
-static void warp_dev_t(const TV *vol, const TF *flow, const TV *ref, int Z, int Y, int X, int C, int order,
-                       float *out)
+template <typename TV, typename TF, typename TR = TV, typename TO = float>
+static void warp_dev_t(const TV *vol, const TF *flow, const TR *ref, int Z, int Y, int X, int C, int order,
+                       TO *out)
 {
     Engine &e = g_eng;
     for (int c = 0; c < C; c++) {
         if (order == 3) {
-            warp_cubic_chan<TV, TF>(e, vol, C, c, flow + 0, flow + 1, flow + 2, 3, 1.0, 1.0, 1.0, ref, Z, Y,
-                                    X, out, C, c);
+            warp_cubic_chan<TV, TF, TR, TO>(e, vol, C, c, flow + 0, flow + 1, flow + 2, 3, 1.0, 1.0, 1.0, ref, Z, Y,
+                                            X, out, C, c);
         } else {
             Span sp(e, FR3D_K_WARP, 24.0 * (double)Z * Y * X, 1, (long long)Z * Y * X);
-            launch_warp_linear<TV, TF>(e.st, vol, C, c, flow + 0, flow + 1, flow + 2, 3, ref, Z, Y, X, out,
-                                       C, c);
+            launch_warp_linear<TV, TF, TR, TO>(e.st, vol, C, c, flow + 0, flow + 1, flow + 2, 3, ref, Z, Y, X, out,
+                                               C, c);
         }
+    }
+}
+
+// The executor's final compensation warp (parallelization/sequential_3d.py:153-170): the RAW volume in
+// its own element type, flow fp32, reference fp32 or fp64, result in the raw type (OutCast, k_warp.hip).
+template <typename TV>
+static void warp_raw_t(const void *vol, const float *flow, const void *ref, int ref_dtype, int Z, int Y, int X, int C,
+                       int order, void *out)
+{
+    if (ref_dtype == FR3D_F64)
+        warp_dev_t<TV, float, double, TV>((const TV *)vol, flow, (const double *)ref, Z, Y, X, C, order, (TV *)out);
+    else
+        warp_dev_t<TV, float, float, TV>((const TV *)vol, flow, (const float *)ref, Z, Y, X, C, order, (TV *)out);
+}
+
+static void warp_raw(const void *vol, int raw_dtype, const float *flow, const void *ref, int ref_dtype, int Z, int Y,
+                     int X, int C, int order, void *out)
+{
+    switch (raw_dtype) {
+        case FR3D_F32: warp_raw_t<float>(vol, flow, ref, ref_dtype, Z, Y, X, C, order, out); break;
+        case FR3D_F64: warp_raw_t<double>(vol, flow, ref, ref_dtype, Z, Y, X, C, order, out); break;
+        case FR3D_U8: warp_raw_t<unsigned char>(vol, flow, ref, ref_dtype, Z, Y, X, C, order, out); break;
+        case FR3D_U16: warp_raw_t<unsigned short>(vol, flow, ref, ref_dtype, Z, Y, X, C, order, out); break;
+        case FR3D_I16: warp_raw_t<short>(vol, flow, ref, ref_dtype, Z, Y, X, C, order, out); break;
+        default: throw Error("unknown dtype code");
     }
 }
 
@@ -698,21 +746,39 @@ static void warp_dev(const void *vol, int vdt, const void *flow, int fdt, const 
     FR3D_HIP(hipStreamSynchronize(g_eng.st));
 }
 
-static void process_batch_dev(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
-                              const float *ref_proc, const float *ref_raw, const float *w_init,
+static size_t dtype_size(int dt)
+{
+    switch (dt) {
+        case FR3D_F32: return 4;
+        case FR3D_F64: return 8;
+        case FR3D_U8: return 1;
+        case FR3D_U16: case FR3D_I16: return 2;
+        default: throw Error("unknown dtype code");
+    }
+}
+
+// The per-volume body of the executors for T device-resident volumes.  batch_raw / registered_out have
+// the element type `raw_dtype`, ref_raw has `ref_dtype` (FR3D_F32 | FR3D_F64).  `rp_in`: reference and
+// weight pyramids built by the caller (the host entry builds them once for all its staging windows).
+static void process_batch_dev(const fr3d_params *p, const float *batch_proc, const void *batch_raw, int raw_dtype,
+                              const float *ref_proc, const void *ref_raw, int ref_dtype, const float *w_init,
                               const float *weight, int T, int Z, int Y, int X, int C, int order,
-                              float *flows_out, float *registered_out, fr3d_progress_fn progress, void *user)
+                              float *flows_out, void *registered_out, fr3d_progress_fn progress, void *user,
+                              const RefPyramid *rp_in = nullptr)
 {
     ensure_init();
     check_params(p, Z, Y, X, C);
     FR3D_CHECK(order == 1 || order == 3, "Unsupported interpolation method. Use 'linear' or 'cubic'.");
     FR3D_CHECK(T >= 0, "T must be >= 0");
+    FR3D_CHECK(ref_dtype == FR3D_F32 || ref_dtype == FR3D_F64, "reference_raw must be float32 or float64");
+    const size_t esz = dtype_size(raw_dtype);
     Engine &e = g_eng;
     int min_level = p->min_level;
     std::vector<Level> lv = make_schedule(Z, Y, X, p->eta, p->levels, min_level);
-    RefPyramid rp;
+    RefPyramid rp_own;
     // the fixed-reference pyramid and the weight pyramid are time-invariant: build once
-    build_ref_pyramid(e, lv, ref_proc, weight, Z, Y, X, C, rp, "pb_");
+    if (!rp_in) build_ref_pyramid(e, lv, ref_proc, weight, Z, Y, X, C, rp_own, "pb_");
+    const RefPyramid &rp = rp_in ? *rp_in : rp_own;
     const size_t nv = (size_t)Z * Y * X;
     g_fp64_storage = solver_mode(*p, C) == 2;
     const int B = T > 0 ? pick_batch(T, lv, C) : 1;
@@ -730,15 +796,67 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
         get_displacement_core(e, *p, lv, min_level, rp, nb, mov.data(), Z, Y, X, C, w_init, fl.data(),
                               g_batch_hint > 0 ? pick_batch(g_batch_hint, lv, C) : B);
         for (int b = 0; b < nb; b++) {
-            const int t = t0 + b;
-            warp_dev_t<float, float>(batch_raw + (size_t)t * nv * C, fl[b], ref_raw, Z, Y, X, C, order,
-                                     registered_out + (size_t)t * nv * C);
+            const size_t o = (size_t)(t0 + b) * nv * C * esz;
+            warp_raw((const char *)batch_raw + o, raw_dtype, fl[b], ref_raw, ref_dtype, Z, Y, X, C, order,
+                     (char *)registered_out + o);
         }
         if (progress) {
             FR3D_HIP(hipStreamSynchronize(e.st));
             for (int b = 0; b < nb; b++) progress(1, user);
         }
     }
+    FR3D_HIP(hipStreamSynchronize(e.st));
+}
+
+// ---- f-4 update_reference (compensate_recording_3D.py:395-429) -------------------------------------
+// new reference_proc = per-channel mean of the last min(100, T) batch_proc volumes warped by their flows.
+template <typename TV, typename TR>
+static void update_reference_t(Engine &e, const TV *batch_proc, const float *flows, const TR *ref_proc, int T, int Z,
+                               int Y, int X, int C, int order, double *new_ref)
+{
+    const size_t nv = (size_t)Z * Y * X;
+    const int n_ref = std::min(100, T);
+    if (n_ref < 1) return;
+    const int start = T - n_ref;
+    float *tmp = e.f32("ur_tmp", nv);
+    double *acc = e.f64("ur_acc", nv);
+    for (int c = 0; c < C; c++) {
+        for (int t = 0; t < n_ref; t++) {
+            const TV *vol = batch_proc + (size_t)(start + t) * nv * C;
+            const float *fl = flows + (size_t)(start + t) * nv * 3;
+            if (order == 3) {
+                warp_cubic_chan<TV, float, TR, float>(e, vol, C, c, fl + 0, fl + 1, fl + 2, 3, 1.0, 1.0, 1.0, ref_proc, Z,
+                                                      Y, X, tmp, 1, 0);
+            } else {
+                // the linear launcher indexes vol and ref with the same channel stride / offset (C, c); tmp is planar
+                Span sp(e, FR3D_K_WARP, 24.0 * (double)nv, 1, (long long)nv);
+                launch_warp_linear<TV, float, TR, float>(e.st, vol, C, c, fl + 0, fl + 1, fl + 2, 3, ref_proc, Z, Y, X, tmp, 1,
+                                                         0);
+            }
+            launch_accum_f64(e.st, acc, tmp, (long long)nv, t == 0);
+        }
+        launch_mean_store(e.st, acc, (long long)nv, C, c, (double)n_ref, new_ref);
+    }
+}
+
+static void update_reference_dev(const void *batch_proc, int proc_dtype, const float *flows, const void *ref_proc,
+                                 int ref_dtype, int T, int Z, int Y, int X, int C, int order, double *new_ref)
+{
+    ensure_init();
+    FR3D_CHECK(order == 1 || order == 3, "Unsupported interpolation method. Use 'linear' or 'cubic'.");
+    FR3D_CHECK(T >= 0 && Z >= 1 && Y >= 1 && X >= 1 && C >= 1, "bad update_reference shape");
+    FR3D_CHECK((T == 0 || (batch_proc && flows)) && ref_proc && new_ref, "NULL pointer");
+    FR3D_CHECK((proc_dtype == FR3D_F32 || proc_dtype == FR3D_F64) && (ref_dtype == FR3D_F32 || ref_dtype == FR3D_F64),
+               "batch_proc / reference_proc must be float32 or float64");
+    Engine &e = g_eng;
+    if (proc_dtype == FR3D_F64 && ref_dtype == FR3D_F64)
+        update_reference_t<double, double>(e, (const double *)batch_proc, flows, (const double *)ref_proc, T, Z, Y, X, C, order, new_ref);
+    else if (proc_dtype == FR3D_F64)
+        update_reference_t<double, float>(e, (const double *)batch_proc, flows, (const float *)ref_proc, T, Z, Y, X, C, order, new_ref);
+    else if (ref_dtype == FR3D_F64)
+        update_reference_t<float, double>(e, (const float *)batch_proc, flows, (const double *)ref_proc, T, Z, Y, X, C, order, new_ref);
+    else
+        update_reference_t<float, float>(e, (const float *)batch_proc, flows, (const float *)ref_proc, T, Z, Y, X, C, order, new_ref);
     FR3D_HIP(hipStreamSynchronize(e.st));
 }
 
@@ -811,17 +929,6 @@ static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int 
         if (out_dtype == FR3D_F64) launch_store_channel<double>(e.st, cur, n, C, c, (double *)out);
         else launch_store_channel<float>(e.st, cur, n, C, c, (float *)out);
         sp.add(8.0 * (double)n * 2.0 * passes, passes + 1, n);
-    }
-}
-
-static size_t dtype_size(int dt)
-{
-    switch (dt) {
-        case FR3D_F32: return 4;
-        case FR3D_F64: return 8;
-        case FR3D_U8: return 1;
-        case FR3D_U16: case FR3D_I16: return 2;
-        default: throw Error("unknown dtype code");
     }
 }
 
@@ -1020,53 +1127,70 @@ int fr3d_warp(const void *vol, int vol_dtype, const void *flow, int flow_dtype, 
     FR3D_CATCH
 }
 
+int fr3d_process_batch_raw_dev(const fr3d_params *p, const float *batch_proc, const void *batch_raw, int raw_dtype,
+                               const float *ref_proc, const void *ref_raw, int ref_dtype, const float *w_init,
+                               const float *weight, int T, int Z, int Y, int X, int C, int order, float *flows_out,
+                               void *registered_out, fr3d_progress_fn progress, void *user)
+{
+    FR3D_TRY
+    FR3D_CHECK(batch_proc && batch_raw && ref_proc && ref_raw && flows_out && registered_out, "NULL pointer");
+    process_batch_dev(p, batch_proc, batch_raw, raw_dtype, ref_proc, ref_raw, ref_dtype, w_init, weight, T, Z, Y, X, C,
+                      order, flows_out, registered_out, progress, user);
+    FR3D_CATCH
+}
+
 int fr3d_process_batch_dev(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
                            const float *ref_proc, const float *ref_raw, const float *w_init,
                            const float *weight, int T, int Z, int Y, int X, int C, int order, float *flows_out,
                            float *registered_out, fr3d_progress_fn progress, void *user)
 {
-    FR3D_TRY
-    FR3D_CHECK(batch_proc && batch_raw && ref_proc && ref_raw && flows_out && registered_out, "NULL pointer");
-    process_batch_dev(p, batch_proc, batch_raw, ref_proc, ref_raw, w_init, weight, T, Z, Y, X, C, order,
-                      flows_out, registered_out, progress, user);
-    FR3D_CATCH
+    return fr3d_process_batch_raw_dev(p, batch_proc, batch_raw, FR3D_F32, ref_proc, ref_raw, FR3D_F32, w_init, weight,
+                                      T, Z, Y, X, C, order, flows_out, registered_out, progress, user);
 }
 
-int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
-                       const float *ref_proc, const float *ref_raw, const float *w_init, const float *weight,
-                       int T, int Z, int Y, int X, int C, int order, float *flows_out, float *registered_out,
-                       fr3d_progress_fn progress, void *user)
+int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const void *batch_raw, int raw_dtype,
+                           const float *ref_proc, const void *ref_raw, int ref_dtype, const float *w_init,
+                           const float *weight, int T, int Z, int Y, int X, int C, int order, float *flows_out,
+                           void *registered_out, fr3d_progress_fn progress, void *user)
 {
     FR3D_TRY
     ensure_init();
     check_params(p, Z, Y, X, C);
     FR3D_CHECK(batch_proc && batch_raw && ref_proc && ref_raw && flows_out && registered_out, "NULL pointer");
     FR3D_CHECK(T >= 0, "T must be >= 0");
+    FR3D_CHECK(ref_dtype == FR3D_F32 || ref_dtype == FR3D_F64, "reference_raw must be float32 or float64");
     const size_t nv = (size_t)Z * Y * X;
+    const size_t rsz = dtype_size(raw_dtype), fsz = dtype_size(ref_dtype);
     Staged s;
     const float *drp = (const float *)s.up(ref_proc, nv * C * 4);
-    const float *drr = (const float *)s.up(ref_raw, nv * C * 4);
+    const void *drr = s.up(ref_raw, nv * C * fsz);
     const float *dwi = (const float *)s.up(w_init, nv * 3 * 4);
     const float *dwt = (const float *)s.up(weight, nv * C * 4);
     // The series passes through the device in windows of one lock-step batch, double-buffered: a
     // copier thread uploads window k+2 and downloads window k on its own stream while the engine
     // stream computes window k+1, so the PCIe traffic (and the page faults of freshly allocated
     // host output arrays) hide behind the solver.  T is bounded by host memory only.
-    const size_t per_vol = nv * 4 * (size_t)(3 * C + 3);
-    const int lock = g_batch_hint > 0 ? g_batch_hint : 4;
+    const size_t per_vol = nv * ((size_t)C * (4 + 2 * rsz) + 12);
+    const int lock = batch_wanted();
     const char *cap_env = getenv("FR3D_STAGE_KIB");  // staging budget override (tests use it to force windows)
     const size_t cap = cap_env ? (size_t)std::max(1, atoi(cap_env)) << 10 : (8ull << 30);
     int win = (int)std::max<size_t>(1, std::min<size_t>((size_t)lock, cap / per_vol));
     if (win > T) win = T;
     const int nwin = win > 0 ? cdiv(T, win) : 0;
     const int nset = nwin > 1 ? 2 : 1;
-    float *dbp[2], *dbr[2], *dfl[2], *dre[2];
+    float *dbp[2], *dfl[2];
+    char *dbr[2], *dre[2];
     for (int q = 0; q < nset; q++) {
         dbp[q] = (float *)s.alloc(nv * C * 4 * (size_t)win);
-        dbr[q] = (float *)s.alloc(nv * C * 4 * (size_t)win);
+        dbr[q] = (char *)s.alloc(nv * C * rsz * (size_t)win);
         dfl[q] = (float *)s.alloc(nv * 3 * 4 * (size_t)win);
-        dre[q] = (float *)s.alloc(nv * C * 4 * (size_t)win);
+        dre[q] = (char *)s.alloc(nv * C * rsz * (size_t)win);
     }
+    // the reference and weight pyramids are the same for every window: build them once
+    int min_level = p->min_level;
+    std::vector<Level> lv = make_schedule(Z, Y, X, p->eta, p->levels, min_level);
+    RefPyramid rp;
+    if (T > 0) build_ref_pyramid(g_eng, lv, drp, dwt, Z, Y, X, C, rp, "pb_");
     std::mutex mu;
     std::condition_variable cv;
     int uploaded = 0, computed = 0;  // windows finished by each side
@@ -1083,7 +1207,8 @@ int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const floa
                 const int q = k % nset, nt = count_of(k);
                 const size_t o = (size_t)k * win * nv * C;
                 FR3D_HIP(hipMemcpyAsync(dbp[q], batch_proc + o, nv * C * 4 * (size_t)nt, hipMemcpyHostToDevice, cs));
-                FR3D_HIP(hipMemcpyAsync(dbr[q], batch_raw + o, nv * C * 4 * (size_t)nt, hipMemcpyHostToDevice, cs));
+                FR3D_HIP(hipMemcpyAsync(dbr[q], (const char *)batch_raw + o * rsz, nv * C * rsz * (size_t)nt,
+                                        hipMemcpyHostToDevice, cs));
                 FR3D_HIP(hipStreamSynchronize(cs));
                 std::lock_guard<std::mutex> lk(mu);
                 uploaded = k + 1;
@@ -1099,8 +1224,8 @@ int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const floa
                 const int q = k % nset, nt = count_of(k);
                 FR3D_HIP(hipMemcpyAsync(flows_out + (size_t)k * win * nv * 3, dfl[q], nv * 3 * 4 * (size_t)nt,
                                         hipMemcpyDeviceToHost, cs));
-                FR3D_HIP(hipMemcpyAsync(registered_out + (size_t)k * win * nv * C, dre[q], nv * C * 4 * (size_t)nt,
-                                        hipMemcpyDeviceToHost, cs));
+                FR3D_HIP(hipMemcpyAsync((char *)registered_out + (size_t)k * win * nv * C * rsz, dre[q],
+                                        nv * C * rsz * (size_t)nt, hipMemcpyDeviceToHost, cs));
                 FR3D_HIP(hipStreamSynchronize(cs));
                 if (k + nset < nwin) upload(k + nset);
             }
@@ -1121,8 +1246,8 @@ int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const floa
                 if (abort_all) break;
             }
             const int q = k % nset;
-            process_batch_dev(p, dbp[q], dbr[q], drp, drr, dwi, dwt, count_of(k), Z, Y, X, C, order, dfl[q], dre[q],
-                              progress, user);  // returns with the engine stream drained
+            process_batch_dev(p, dbp[q], dbr[q], raw_dtype, drp, drr, ref_dtype, dwi, dwt, count_of(k), Z, Y, X, C, order,
+                              dfl[q], dre[q], progress, user, &rp);  // returns with the engine stream drained
             std::lock_guard<std::mutex> lk(mu);
             computed = k + 1;
             cv.notify_all();
@@ -1136,6 +1261,47 @@ int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const floa
     copier.join();
     if (main_error) std::rethrow_exception(main_error);
     if (copier_error) std::rethrow_exception(copier_error);
+    FR3D_CATCH
+}
+
+int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
+                       const float *ref_proc, const float *ref_raw, const float *w_init, const float *weight,
+                       int T, int Z, int Y, int X, int C, int order, float *flows_out, float *registered_out,
+                       fr3d_progress_fn progress, void *user)
+{
+    return fr3d_process_batch_raw(p, batch_proc, batch_raw, FR3D_F32, ref_proc, ref_raw, FR3D_F32, w_init, weight, T, Z,
+                                  Y, X, C, order, flows_out, registered_out, progress, user);
+}
+
+int fr3d_update_reference_dev(const void *batch_proc, int proc_dtype, const float *flows, const void *ref_proc,
+                              int ref_dtype, int T, int Z, int Y, int X, int C, int order, double *new_ref)
+{
+    FR3D_TRY
+    update_reference_dev(batch_proc, proc_dtype, flows, ref_proc, ref_dtype, T, Z, Y, X, C, order, new_ref);
+    FR3D_CATCH
+}
+
+int fr3d_update_reference(const void *batch_proc, int proc_dtype, const float *flows, const void *ref_proc,
+                          int ref_dtype, int T, int Z, int Y, int X, int C, int order, double *new_ref)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(T >= 0 && Z >= 1 && Y >= 1 && X >= 1 && C >= 1, "bad update_reference shape");
+    FR3D_CHECK((T == 0 || (batch_proc && flows)) && ref_proc && new_ref, "NULL pointer");
+    FR3D_CHECK((proc_dtype == FR3D_F32 || proc_dtype == FR3D_F64) && (ref_dtype == FR3D_F32 || ref_dtype == FR3D_F64),
+               "batch_proc / reference_proc must be float32 or float64");
+    const size_t nv = (size_t)Z * Y * X;
+    const int n_ref = std::min(100, T);
+    if (n_ref < 1) return 0;  // the reference returns without touching reference_proc (:398-399)
+    const size_t psz = dtype_size(proc_dtype), rsz = dtype_size(ref_dtype);
+    Staged s;
+    // only the last n_ref volumes are read
+    const void *dbp = s.up((const char *)batch_proc + (size_t)(T - n_ref) * nv * C * psz, (size_t)n_ref * nv * C * psz);
+    const float *dfl = (const float *)s.up(flows + (size_t)(T - n_ref) * nv * 3, (size_t)n_ref * nv * 3 * 4);
+    const void *drp = s.up(ref_proc, nv * C * rsz);
+    double *dout = (double *)s.alloc(nv * C * 8);
+    update_reference_dev(dbp, proc_dtype, dfl, drp, ref_dtype, n_ref, Z, Y, X, C, order, dout);
+    FR3D_HIP(hipMemcpy(new_ref, dout, nv * C * 8, hipMemcpyDeviceToHost));
     FR3D_CATCH
 }
 
@@ -1294,8 +1460,18 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     FR3D_HIP(hipMemsetAsync(db, 0, ns * 3 * 4, e.st));
     a.iterations = iterations;
     a.update_lag = update_lag;
+    float *dres = db;
     if (a_smooth == 1.0) {
-        launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
+        const int pair_rows = sor_kernel_choice(sk);
+        if (pair_rows) {
+            float *db2 = (float *)s.alloc(ns * 3 * 4);
+            FR3D_HIP(hipMemsetAsync(db2, 0, ns * 3 * 4, e.st));
+            for (int d = 0; d < 3; d++) a.dB[d] = db2 + (size_t)d * ns;
+            if (sor_pair_result(iterations)) dres = db2;
+            launch_sor_pair<float>(e.st, a, solver_fp64 != 0, e.pair_sched(sk, iterations, pair_rows));
+        } else {
+            launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
+        }
     } else {
         float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);
         SmoothArgs<float> sa;
@@ -1321,7 +1497,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
         if (iterations > 0)
             FR3D_HIP(hipMemcpyAsync(db, sa.D[(iterations - 1) % 3][0], ns * 3 * 4, hipMemcpyDeviceToDevice, e.st));
     }
-    launch_unskew_copy_n<float, float>(e.st, db, (long long)ns, dn, (long long)n, 3, sk);
+    launch_unskew_copy_n<float, float>(e.st, dres, (long long)ns, dn, (long long)n, 3, sk);
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 4, hipMemcpyDeviceToHost));
     FR3D_CATCH

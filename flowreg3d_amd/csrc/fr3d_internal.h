@@ -30,6 +30,9 @@ struct Error : std::runtime_error {
         if (!(cond)) throw ::fr3d::Error(std::string(msg));                                     \
     } while (0)
 
+// after a kernel launch: a rejected launch (bad grid, too much LDS, ...) must not return rc = 0
+#define FR3D_LAUNCH_CHECK() FR3D_HIP(hipGetLastError())
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------
@@ -86,7 +89,8 @@ struct SorArgsT {
     const S *A[12 * FR3D_MAX_CHANNELS];
     const S *weight[FR3D_MAX_CHANNELS];
     const S *L[3];  // alpha-weighted Laplacian of u,v,w (constant over the iterations)
-    S *d[3];        // du,dv,dw, updated in place
+    S *d[3];        // du,dv,dw: updated in place by k_sor_step; buffer of the even iterations of k_sor_pair
+    S *dB[3];       // k_sor_pair only: buffer of the odd iterations (increments double-buffered by parity)
     Skew sk;
     double ax, ay, az;  // alpha/h^2
     double a_data[FR3D_MAX_CHANNELS];
@@ -142,15 +146,16 @@ template <typename T>
 void launch_pad_edge(hipStream_t st, const T *src, int cs, int co, int Z, int Y, int X, int npad,
                      double *dst);
 void launch_prefilter3(hipStream_t st, double *c, int PZ, int PY, int PX);
-// flow components pu/pv/pw with element stride fs; displacement = value / h (per axis)
-template <typename TF, typename TR>
+// flow components pu/pv/pw with element stride fs; displacement = value / h (per axis).  TO = float
+// inside the pyramid; the executor tail writes the raw volume's own element type (OutCast in k_warp.hip)
+template <typename TF, typename TR, typename TO>
 void launch_warp_cubic(hipStream_t st, const double *coef, int npad, const TF *pu, const TF *pv,
                        const TF *pw, int fs, double hx, double hy, double hz, const TR *ref,
-                       int rcs, int rco, int Z, int Y, int X, float *out, int ocs, int oco);
-template <typename TV, typename TF>
+                       int rcs, int rco, int Z, int Y, int X, TO *out, int ocs, int oco);
+template <typename TV, typename TF, typename TR, typename TO>
 void launch_warp_linear(hipStream_t st, const TV *vol, int vcs, int vco, const TF *pu,
-                        const TF *pv, const TF *pw, int fs, const TV *ref, int Z, int Y, int X,
-                        float *out, int ocs, int oco);
+                        const TF *pv, const TF *pw, int fs, const TR *ref, int Z, int Y, int X,
+                        TO *out, int ocs, int oco);
 
 // K3 motion tensor: f1,f2 planar (Z,Y,X) fp32.  Jout[a] for a = J11,J22,J33,J44,J12,J13,J23,
 // J14,J24,J34; A (nullable): 12 factor arrays a_stride apart; written skewed (sk != nullptr) or
@@ -205,10 +210,20 @@ int sor_tile_rows(const Skew &sk);
 // iteration t works on hyperplane tau - lag*t in launch tau (lag 2: a_smooth == 1 kernel; lag 4 = SM_LAG:
 // the a_smooth != 1 kernels, whose P-stage and sweep share one schedule two launches apart)
 SorSched build_sor_schedule(const Skew &sk, int iterations, int by, int lag = 2);
+// two hyperplanes per launch (k_sor_pair.hip): tiles of `rows` (6 or 14) rows x 64 lanes, lag 3
+SorSched build_sor_pair_schedule(const Skew &sk, int iterations, int rows);
 void free_sor_schedule(SorSched &s);
 // Runs all `iterations` pipelined hyperplane steps.  Returns the number of kernel launches.
 template <typename S>
 long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorSched &sched);
+
+// Pair sweep: needs a.dB; the final increments are in a.d when `iterations` is odd... see sor_pair_result().
+template <typename S>
+long long launch_sor_pair(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorSched &sched);
+// which buffer holds the increments after `iterations` pair-sweep iterations: 0 = a.d, 1 = a.dB
+static inline int sor_pair_result(int iterations) { return iterations > 0 ? ((iterations - 1) & 1) : 0; }
+// 0: k_sor_step (one hyperplane per launch), 6 / 14: k_sor_pair with that many rows per tile
+int sor_kernel_choice(const Skew &sk);
 
 // K8 median (natural layout)
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);
@@ -222,6 +237,10 @@ void launch_store_channel(hipStream_t st, const double *in, long long n, int C, 
 
 // f-2 statistics (k_misc.hip): partial = nblocks x 6 doubles (sum|w|, max|w|, sum div, sum u, sum v, sum w)
 void launch_flow_stats(hipStream_t st, const float *flow, int Z, int Y, int X, int nblocks, double *partial);
+
+// f-4 update_reference: acc = first ? x : acc + x (fp64), out[t*C+c] = acc[t] / count
+void launch_accum_f64(hipStream_t st, double *acc, const float *x, long long n, bool first);
+void launch_mean_store(hipStream_t st, const double *acc, long long n, int C, int c, double count, double *out);
 
 // K9 pointwise helpers
 void launch_axpy(hipStream_t st, float *y, const float *x, long long n);  // y += x

@@ -51,6 +51,31 @@ k_unpack(const float *__restrict__ inter, int C, long long n, float *__restrict_
     planar[t] = inter[(size_t)v * C + c];
 }
 
+// f-4 update_reference (compensate_recording_3D.py:395-429): the fp64 stack mean, volume by volume in
+// stack order like np.mean(axis=0): acc = x0, acc += x1, ... ; out = acc / n
+__global__ void __launch_bounds__(256)
+k_accum_f64(double *__restrict__ acc, const float *__restrict__ x, long long n, int first)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) acc[t] = first ? (double)x[t] : acc[t] + (double)x[t];
+}
+__global__ void __launch_bounds__(256)
+k_mean_store(const double *__restrict__ acc, long long n, int C, int c, double count, double *__restrict__ out)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[(size_t)t * C + c] = acc[t] / count;
+}
+void launch_accum_f64(hipStream_t st, double *acc, const float *x, long long n, bool first)
+{
+    if (n > 0) hipLaunchKernelGGL(k_accum_f64, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, x, n, first ? 1 : 0);
+    FR3D_LAUNCH_CHECK();
+}
+void launch_mean_store(hipStream_t st, const double *acc, long long n, int C, int c, double count, double *out)
+{
+    if (n > 0) hipLaunchKernelGGL(k_mean_store, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, n, C, c, count, out);
+    FR3D_LAUNCH_CHECK();
+}
+
 void launch_axpy(hipStream_t st, float *y, const float *x, long long n)
 {
     if (n > 0) hipLaunchKernelGGL(k_axpy, dim3(cdiv(n, 256)), dim3(256), 0, st, y, x, n);

@@ -23,6 +23,7 @@
 // the u,v,w part of the stencil is iteration-invariant and precomputed once (k_laplace).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "fr3d_internal.h"
 #include "k_sor_core.h"
@@ -115,6 +116,20 @@ static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo,
         default: throw Error("SOR kernel is instantiated for 1..4 channels");
     }
 #undef FR3D_SOR_CASE
+}
+
+int sor_kernel_choice(const Skew &sk)
+{
+    // FR3D_SOR_KERNEL: "step" = one hyperplane per launch (k_sor_step), "pair6"/"pair14" = two hyperplanes
+    // per launch with 6 or 14 rows per tile (k_sor_pair.hip).  Results are bit-identical.
+    const char *env = getenv("FR3D_SOR_KERNEL");
+    (void)sk;
+    if (env) {
+        if (!strcmp(env, "step")) return 0;
+        if (!strcmp(env, "pair6")) return 6;
+        if (!strcmp(env, "pair14")) return 14;
+    }
+    return 0;
 }
 
 int sor_tile_rows(const Skew &sk)

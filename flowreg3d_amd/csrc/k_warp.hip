@@ -44,6 +44,9 @@ void launch_pad_edge(hipStream_t st, const T *src, int cs, int co, int Z, int Y,
 }
 template void launch_pad_edge<float>(hipStream_t, const float *, int, int, int, int, int, int, double *);
 template void launch_pad_edge<double>(hipStream_t, const double *, int, int, int, int, int, int, double *);
+template void launch_pad_edge<unsigned char>(hipStream_t, const unsigned char *, int, int, int, int, int, int, double *);
+template void launch_pad_edge<unsigned short>(hipStream_t, const unsigned short *, int, int, int, int, int, int, double *);
+template void launch_pad_edge<short>(hipStream_t, const short *, int, int, int, int, int, int, double *);
 
 // ---- 2. prefilter -----------------------------------------------------------------------------
 // One line in place.  `c` points at element 0, consecutive elements are `stride` apart.
@@ -273,15 +276,60 @@ __device__ __forceinline__ void bspline3_weights(double cc, double *w, int *star
     w[3] = w3;
 }
 
+// Output conversion.  The executors warp the RAW volume (parallelization/sequential_3d.py:153-170):
+// scipy.ndimage.map_coordinates allocates its output in the INPUT's dtype, so the interpolated double
+// goes through NI_GeometricTransform's output cast (ni_interpolation.c CASE_INTERP_OUT_*: unsigned
+// t > 0 ? t + 0.5 : 0, clamped, truncated; signed t +- 0.5, clamped, truncated; float/double plain cast),
+// then into the float32 `warped` array (core/optical_flow_3d.py:59-66) and into `registered` of the
+// batch's dtype.  Out-of-bounds voxels take the reference value through float32 (:69-70) and NumPy's
+// float -> integer cast (truncation).  Inside the pyramid everything is float (TO = float).
+template <typename TO> struct OutCast;
+template <> struct OutCast<float> {
+    static __device__ __forceinline__ float interp(double t) { return (float)t; }
+    static __device__ __forceinline__ float oob(float f) { return f; }
+};
+template <> struct OutCast<double> {
+    static __device__ __forceinline__ double interp(double t) { return (double)(float)t; }
+    static __device__ __forceinline__ double oob(float f) { return (double)f; }
+};
+template <> struct OutCast<unsigned char> {
+    static __device__ __forceinline__ unsigned char interp(double t)
+    {
+        t = t > 0 ? t + 0.5 : 0;
+        t = t > 255.0 ? 255.0 : t;
+        return (unsigned char)t;
+    }
+    static __device__ __forceinline__ unsigned char oob(float f) { return (unsigned char)f; }
+};
+template <> struct OutCast<unsigned short> {
+    static __device__ __forceinline__ unsigned short interp(double t)
+    {
+        t = t > 0 ? t + 0.5 : 0;
+        t = t > 65535.0 ? 65535.0 : t;
+        return (unsigned short)t;
+    }
+    static __device__ __forceinline__ unsigned short oob(float f) { return (unsigned short)f; }
+};
+template <> struct OutCast<short> {
+    static __device__ __forceinline__ short interp(double t)
+    {
+        t = t > 0 ? t + 0.5 : t - 0.5;
+        t = t > 32767.0 ? 32767.0 : t;
+        t = t < -32768.0 ? -32768.0 : t;
+        return (short)t;
+    }
+    static __device__ __forceinline__ short oob(float f) { return (short)f; }
+};
+
 #ifndef WARP_ZB
 #define WARP_ZB 1  // z-taps whose 16 coefficients are in flight together
 #endif
-template <typename TF, typename TR>
+template <typename TF, typename TR, typename TO>
 __global__ void __launch_bounds__(256)
 k_warp_cubic(const double *__restrict__ coef, int npad, const TF *__restrict__ pu,
              const TF *__restrict__ pv, const TF *__restrict__ pw, int fs, double hx, double hy,
              double hz, const TR *__restrict__ ref, int rcs, int rco, int Z, int Y, int X,
-             float *__restrict__ out, int ocs, int oco)
+             TO *__restrict__ out, int ocs, int oco)
 {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long total = (long long)Z * Y * X;
@@ -297,7 +345,7 @@ k_warp_cubic(const double *__restrict__ coef, int npad, const TF *__restrict__ p
     bool oob = (mx < 0.0f) || (mx >= (float)X) || (my < 0.0f) || (my >= (float)Y) ||
                (mz < 0.0f) || (mz >= (float)Z);
     if (oob) {
-        out[(size_t)t * ocs + oco] = (float)ref[(size_t)t * rcs + rco];
+        out[(size_t)t * ocs + oco] = OutCast<TO>::oob((float)ref[(size_t)t * rcs + rco]);
         return;
     }
     float cx = mx > (float)(X - 1) ? (float)(X - 1) : mx;
@@ -343,41 +391,44 @@ k_warp_cubic(const double *__restrict__ coef, int npad, const TF *__restrict__ p
                     acc += cf;
                 }
     }
-    out[(size_t)t * ocs + oco] = (float)acc;
+    out[(size_t)t * ocs + oco] = OutCast<TO>::interp(acc);
 }
 
-template <typename TF, typename TR>
+template <typename TF, typename TR, typename TO>
 void launch_warp_cubic(hipStream_t st, const double *coef, int npad, const TF *pu, const TF *pv,
                        const TF *pw, int fs, double hx, double hy, double hz, const TR *ref,
-                       int rcs, int rco, int Z, int Y, int X, float *out, int ocs, int oco)
+                       int rcs, int rco, int Z, int Y, int X, TO *out, int ocs, int oco)
 {
     long long total = (long long)Z * Y * X;
-    hipLaunchKernelGGL((k_warp_cubic<TF, TR>), dim3(cdiv(total, 256)), dim3(256), 0, st, coef,
+    hipLaunchKernelGGL((k_warp_cubic<TF, TR, TO>), dim3(cdiv(total, 256)), dim3(256), 0, st, coef,
                        npad, pu, pv, pw, fs, hx, hy, hz, ref, rcs, rco, Z, Y, X, out, ocs, oco);
+    FR3D_LAUNCH_CHECK();
 }
-template void launch_warp_cubic<float, float>(hipStream_t, const double *, int, const float *,
-                                              const float *, const float *, int, double, double,
-                                              double, const float *, int, int, int, int, int,
-                                              float *, int, int);
-template void launch_warp_cubic<double, float>(hipStream_t, const double *, int, const double *,
-                                               const double *, const double *, int, double, double,
-                                               double, const float *, int, int, int, int, int,
-                                               float *, int, int);
-template void launch_warp_cubic<float, double>(hipStream_t, const double *, int, const float *,
-                                               const float *, const float *, int, double, double,
-                                               double, const double *, int, int, int, int, int,
-                                               float *, int, int);
-template void launch_warp_cubic<double, double>(hipStream_t, const double *, int, const double *,
-                                                const double *, const double *, int, double,
-                                                double, double, const double *, int, int, int, int,
-                                                int, float *, int, int);
+#define FR3D_WARP_CUBIC_INST(TF, TR, TO)                                                                       \
+    template void launch_warp_cubic<TF, TR, TO>(hipStream_t, const double *, int, const TF *, const TF *, const TF *, \
+                                                int, double, double, double, const TR *, int, int, int, int, int,  \
+                                                TO *, int, int);
+FR3D_WARP_CUBIC_INST(float, float, float)
+FR3D_WARP_CUBIC_INST(double, float, float)
+FR3D_WARP_CUBIC_INST(float, double, float)
+FR3D_WARP_CUBIC_INST(double, double, float)
+// the executor's final warp of a raw volume: float32 flow, reference f32/f64, output in the raw dtype
+FR3D_WARP_CUBIC_INST(float, float, double)
+FR3D_WARP_CUBIC_INST(float, double, double)
+FR3D_WARP_CUBIC_INST(float, float, unsigned char)
+FR3D_WARP_CUBIC_INST(float, double, unsigned char)
+FR3D_WARP_CUBIC_INST(float, float, unsigned short)
+FR3D_WARP_CUBIC_INST(float, double, unsigned short)
+FR3D_WARP_CUBIC_INST(float, float, short)
+FR3D_WARP_CUBIC_INST(float, double, short)
+#undef FR3D_WARP_CUBIC_INST
 
 // order 1: no prefilter, no padding; taps clamped like mode="nearest"
-template <typename TV, typename TF>
+template <typename TV, typename TF, typename TR, typename TO>
 __global__ void __launch_bounds__(256)
 k_warp_linear(const TV *__restrict__ vol, int vcs, int vco, const TF *__restrict__ pu,
               const TF *__restrict__ pv, const TF *__restrict__ pw, int fs,
-              const TV *__restrict__ ref, int Z, int Y, int X, float *__restrict__ out, int ocs,
+              const TR *__restrict__ ref, int Z, int Y, int X, TO *__restrict__ out, int ocs,
               int oco)
 {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -393,7 +444,7 @@ k_warp_linear(const TV *__restrict__ vol, int vcs, int vco, const TF *__restrict
     bool oob = (mx < 0.0f) || (mx >= (float)X) || (my < 0.0f) || (my >= (float)Y) ||
                (mz < 0.0f) || (mz >= (float)Z);
     if (oob) {
-        out[(size_t)t * ocs + oco] = (float)ref[(size_t)t * vcs + vco];
+        out[(size_t)t * ocs + oco] = OutCast<TO>::oob((float)ref[(size_t)t * vcs + vco]);
         return;
     }
     double cc[3] = {(double)(mz > (float)(Z - 1) ? (float)(Z - 1) : mz),
@@ -426,31 +477,37 @@ k_warp_linear(const TV *__restrict__ vol, int vcs, int vco, const TF *__restrict
             }
         }
     }
-    out[(size_t)t * ocs + oco] = (float)acc;
+    out[(size_t)t * ocs + oco] = OutCast<TO>::interp(acc);
 }
 
-template <typename TV, typename TF>
+template <typename TV, typename TF, typename TR, typename TO>
 void launch_warp_linear(hipStream_t st, const TV *vol, int vcs, int vco, const TF *pu,
-                        const TF *pv, const TF *pw, int fs, const TV *ref, int Z, int Y, int X,
-                        float *out, int ocs, int oco)
+                        const TF *pv, const TF *pw, int fs, const TR *ref, int Z, int Y, int X,
+                        TO *out, int ocs, int oco)
 {
     long long total = (long long)Z * Y * X;
-    hipLaunchKernelGGL((k_warp_linear<TV, TF>), dim3(cdiv(total, 256)), dim3(256), 0, st, vol, vcs,
+    hipLaunchKernelGGL((k_warp_linear<TV, TF, TR, TO>), dim3(cdiv(total, 256)), dim3(256), 0, st, vol, vcs,
                        vco, pu, pv, pw, fs, ref, Z, Y, X, out, ocs, oco);
+    FR3D_LAUNCH_CHECK();
 }
-template void launch_warp_linear<float, float>(hipStream_t, const float *, int, int, const float *,
-                                               const float *, const float *, int, const float *,
-                                               int, int, int, float *, int, int);
-template void launch_warp_linear<float, double>(hipStream_t, const float *, int, int,
-                                                const double *, const double *, const double *,
-                                                int, const float *, int, int, int, float *, int,
-                                                int);
-template void launch_warp_linear<double, float>(hipStream_t, const double *, int, int,
-                                                const float *, const float *, const float *, int,
-                                                const double *, int, int, int, float *, int, int);
-template void launch_warp_linear<double, double>(hipStream_t, const double *, int, int,
-                                                 const double *, const double *, const double *,
-                                                 int, const double *, int, int, int, float *, int,
-                                                 int);
+#define FR3D_WARP_LINEAR_INST(TV, TF, TR, TO)                                                                    \
+    template void launch_warp_linear<TV, TF, TR, TO>(hipStream_t, const TV *, int, int, const TF *, const TF *,  \
+                                                     const TF *, int, const TR *, int, int, int, TO *, int, int);
+FR3D_WARP_LINEAR_INST(float, float, float, float)
+FR3D_WARP_LINEAR_INST(float, double, float, float)
+FR3D_WARP_LINEAR_INST(double, float, double, float)
+FR3D_WARP_LINEAR_INST(double, double, double, float)
+// raw volumes (executor tail): float32 flow, reference f32/f64, output in the raw dtype
+FR3D_WARP_LINEAR_INST(float, float, double, float)
+FR3D_WARP_LINEAR_INST(double, float, float, float)
+FR3D_WARP_LINEAR_INST(double, float, float, double)
+FR3D_WARP_LINEAR_INST(double, float, double, double)
+FR3D_WARP_LINEAR_INST(unsigned char, float, float, unsigned char)
+FR3D_WARP_LINEAR_INST(unsigned char, float, double, unsigned char)
+FR3D_WARP_LINEAR_INST(unsigned short, float, float, unsigned short)
+FR3D_WARP_LINEAR_INST(unsigned short, float, double, unsigned short)
+FR3D_WARP_LINEAR_INST(short, float, float, short)
+FR3D_WARP_LINEAR_INST(short, float, double, short)
+#undef FR3D_WARP_LINEAR_INST
 
 }  // namespace fr3d

@@ -29,6 +29,10 @@ from . import _lib
 from .core import _order_of, expand_weight
 
 
+_RAW_CODES = {np.dtype(np.float32): _lib.F32, np.dtype(np.float64): _lib.F64, np.dtype(np.uint8): _lib.U8,
+              np.dtype(np.uint16): _lib.U16, np.dtype(np.int16): _lib.I16}
+
+
 class _LocalRuntimeContext:
     """The two registry methods of flowreg3d._runtime.RuntimeContext (:149-199), dotted-path
     storage included, for use when flowreg3d itself is not installed."""
@@ -97,10 +101,11 @@ class HipExecutor3D:
         return False
 
     @classmethod
-    def register(cls) -> bool:
+    def register(cls, force: bool = False) -> bool:
         """Register as ``hip3d``.  Declines (returns False) when no GPU / library is usable so the
-        pipeline's fallback chain (compensate_recording_3D.py:95-118) picks ``sequential3d``."""
-        if _lib.device_count() < 1:
+        pipeline's fallback chain (compensate_recording_3D.py:95-118) picks ``sequential3d``;
+        ``force`` registers regardless (registry tests on machines without a GPU)."""
+        if not force and _lib.device_count() < 1:
             return False
         instance_name = cls.__name__.replace("Executor", "").lower()
         runtime_context().register_parallelization_executor(instance_name, cls)
@@ -140,18 +145,26 @@ class HipExecutor3D:
                 raise ValueError(f"array has shape {a.shape}, expected {shape}")
             return a
 
-        bp = f32(batch_proc, (T, Z, Y, X, nc))
-        br = f32(batch, (T, Z, Y, X, nc))
+        bp = f32(batch_proc, (T, Z, Y, X, nc))  # the reference casts to fp32 itself (util/resize_util_3D.py:116)
         rp = f32(np.asarray(reference_proc).reshape(Z, Y, X, nc), (Z, Y, X, nc))
-        rr = f32(np.asarray(reference_raw).reshape(Z, Y, X, nc), (Z, Y, X, nc))
         wi = None if w_init is None else f32(w_init, (Z, Y, X, 3))
         w32 = None if wt is None else f32(wt, (Z, Y, X, nc))
+        # The final warp works on the RAW volume in its own dtype (sequential_3d.py:153-170): SciPy builds
+        # the spline from the raw values and allocates map_coordinates' output in the input's dtype, so
+        # integer batches are rounded and saturated, not truncated.  float32 / float64 / uint8 / uint16 /
+        # int16 go to the device as they are; anything else is widened to float64 first.
+        raw_code = _RAW_CODES.get(batch.dtype)
+        br = np.ascontiguousarray(batch if raw_code is not None else batch.astype(np.float64))
+        if br.shape != (T, Z, Y, X, nc):
+            raise ValueError(f"array has shape {br.shape}, expected {(T, Z, Y, X, nc)}")
+        code = raw_code if raw_code is not None else _lib.F64
+        rr = np.asarray(reference_raw).reshape(Z, Y, X, nc)
+        rr = np.ascontiguousarray(rr, dtype=np.float32 if rr.dtype == np.float32 else np.float64)
+        ref_code = _lib.F32 if rr.dtype == np.float32 else _lib.F64
         flows = np.empty((T, Z, Y, X, 3), np.float32)
-        # registered[t] = reg_volume stores fp32 into an array of batch.dtype (sequential_3d.py:75,163-170):
-        # a float32 batch receives the device result directly, other dtypes go through one cast
-        registered = np.empty_like(batch)
-        direct = registered.dtype == np.float32 and registered.flags.c_contiguous
-        reg32 = registered if direct else np.empty((T, Z, Y, X, nc), np.float32)
+        registered = np.empty_like(batch)  # np.empty_like(batch), sequential_3d.py:75
+        direct = raw_code is not None and registered.flags.c_contiguous
+        reg_dev = registered if direct else np.empty((T, Z, Y, X, nc), br.dtype)
 
         cb_error = []
 
@@ -164,11 +177,11 @@ class HipExecutor3D:
 
         cb = _lib.PROGRESS_FN(_progress)
         lib = self._lib or _lib.init(self.device)
-        _lib.check(lib.fr3d_process_batch(C.byref(params), _lib.ptr(bp), _lib.ptr(br), _lib.ptr(rp), _lib.ptr(rr),
-                                          _lib.ptr(wi), _lib.ptr(w32), T, Z, Y, X, nc, order, _lib.ptr(flows),
-                                          _lib.ptr(reg32), cb, None))
+        _lib.check(lib.fr3d_process_batch_raw(C.byref(params), _lib.ptr(bp), _lib.ptr(br), code, _lib.ptr(rp),
+                                              _lib.ptr(rr), ref_code, _lib.ptr(wi), _lib.ptr(w32), T, Z, Y, X, nc, order,
+                                              _lib.ptr(flows), _lib.ptr(reg_dev), cb, None))
         if cb_error:
             raise cb_error[0]
         if not direct:
-            registered[...] = reg32
+            registered[...] = reg_dev
         return registered, flows

@@ -48,6 +48,7 @@ class Options:
     channel_normalization: str = "together"
     interpolation_method: str = "cubic"
     update_initialization_w: bool = True
+    update_reference: bool = False
     solver_fp64: Optional[int] = None  # extension: None = fp32 solver storage (fp64 update arithmetic) for one channel, fp64 storage for several
 
     @property
@@ -110,6 +111,28 @@ def flow_statistics(w: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray, 
     _lib.check(lib.fr3d_flow_stats(_lib.ptr(w), T, Z, Y, X, out.ctypes.data_as(C.POINTER(C.c_double))))
     trans = np.sqrt(out[:, 3] ** 2 + out[:, 4] ** 2 + out[:, 5] ** 2)
     return out[:, 0], out[:, 1], out[:, 2], trans
+
+
+def update_reference(batch_proc: np.ndarray, w: np.ndarray, reference_proc: np.ndarray,
+                     interpolation_method: str = "cubic") -> np.ndarray:
+    """``BatchMotionCorrector._update_reference`` (compensate_recording_3D.py:395-429) on the device: per
+    channel the last <= 100 ``batch_proc`` volumes are warped by their flows ``w`` (T,Z,Y,X,3) and averaged in
+    float64 -> new ``reference_proc`` (Z,Y,X,C) float64.  An empty batch returns the reference unchanged."""
+    from .core import _order_of
+    bp = np.asarray(batch_proc)
+    bp = np.ascontiguousarray(bp, dtype=np.float32 if bp.dtype == np.float32 else np.float64)
+    rp = np.asarray(reference_proc)
+    rp = np.ascontiguousarray(rp, dtype=np.float32 if rp.dtype == np.float32 else np.float64)
+    fl = np.ascontiguousarray(w, dtype=np.float32)
+    T, Z, Y, X, nc = bp.shape
+    if rp.shape != (Z, Y, X, nc) or fl.shape != (T, Z, Y, X, 3):
+        raise ValueError(f"incompatible shapes {bp.shape} / {fl.shape} / {rp.shape}")
+    out = rp.astype(np.float64)  # a copy; stays as it is when T == 0
+    lib = _lib.init()
+    _lib.check(lib.fr3d_update_reference(_lib.ptr(bp), _lib.F32 if bp.dtype == np.float32 else _lib.F64, _lib.ptr(fl),
+                                         _lib.ptr(rp), _lib.F32 if rp.dtype == np.float32 else _lib.F64, T, Z, Y, X, nc,
+                                         _order_of(interpolation_method), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
 
 
 class BatchMotionCorrectorHip:
@@ -191,6 +214,9 @@ class BatchMotionCorrectorHip:
                 self.stats.mean_translation.extend(tr.tolist())
                 registered[t0:t0 + bs] = reg
                 flows[t0:t0 + bs] = w
+                if bool(_opt(self.options, "update_reference", False)):  # compensate_recording_3D.py:525-526
+                    self.reference_proc = update_reference(batch_proc, w, self.reference_proc,
+                                                           str(_opt(self.options, "interpolation_method", "cubic")))
         finally:
             self.executor.cleanup()
         return registered, flows

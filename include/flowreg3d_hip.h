@@ -112,6 +112,24 @@ int fr3d_process_batch_dev(const fr3d_params *p, const float *batch_proc, const 
                            float *flows_out, float *registered_out, fr3d_progress_fn progress,
                            void *user);
 
+/* The same with the raw series in its own element type, as the executors hand it over
+ * (parallelization/sequential_3d.py:153-170 warps `batch[t]` itself): batch_raw and registered_out are
+ * (T,Z,Y,X,C) of raw_dtype (FR3D_F32|F64|U8|U16|I16), ref_raw is (Z,Y,X,C) of ref_dtype (F32|F64; the
+ * reference pipeline keeps it in float64).  The spline coefficients are computed from the raw values in
+ * fp64 and the result is stored the way SciPy + the reference store it for that dtype: integer types
+ * round half up / half away from zero and saturate (map_coordinates allocates its output in the input's
+ * dtype), float64 holds the float32-rounded value, out-of-bounds voxels take ref_raw through float32. */
+int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const void *batch_raw,
+                           int raw_dtype, const float *ref_proc, const void *ref_raw, int ref_dtype,
+                           const float *w_init, const float *weight, int T, int Z, int Y, int X, int C,
+                           int order, float *flows_out, void *registered_out,
+                           fr3d_progress_fn progress, void *user);
+int fr3d_process_batch_raw_dev(const fr3d_params *p, const float *batch_proc, const void *batch_raw,
+                               int raw_dtype, const float *ref_proc, const void *ref_raw, int ref_dtype,
+                               const float *w_init, const float *weight, int T, int Z, int Y, int X,
+                               int C, int order, float *flows_out, void *registered_out,
+                               fr3d_progress_fn progress, void *user);
+
 /* Preprocessing in front of the flow path (SURVEY section 8 f-1;
  * motion_correction/compensate_recording_3D.py:229-254): per channel c
  *   out = gaussian_filter((frames - norm_min[c]) / norm_den[c], sigma, mode="reflect", truncate)
@@ -126,6 +144,18 @@ int fr3d_preprocess(const void *frames, int dtype, int T, int Z, int Y, int X, i
 int fr3d_preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C,
                         const double *norm_min, const double *norm_den, const double *sigma,
                         double truncate, void *out, int out_dtype);
+
+/* Reference update of the batch driver (BatchMotionCorrector._update_reference,
+ * motion_correction/compensate_recording_3D.py:395-429): per channel, the last min(100,T) volumes of
+ * batch_proc are warped by their flows (imregister_wrapper, fp32 result; out-of-bounds voxels from the
+ * current reference_proc) and averaged in fp64 in stack order.  batch_proc: (T,Z,Y,X,C) of proc_dtype
+ * (FR3D_F32|F64); flows: (T,Z,Y,X,3) fp32; ref_proc: (Z,Y,X,C) of ref_dtype; new_ref: (Z,Y,X,C) fp64 (left
+ * untouched when T == 0, like the reference).  new_ref must not alias ref_proc. */
+int fr3d_update_reference(const void *batch_proc, int proc_dtype, const float *flows, const void *ref_proc,
+                          int ref_dtype, int T, int Z, int Y, int X, int C, int order, double *new_ref);
+int fr3d_update_reference_dev(const void *batch_proc, int proc_dtype, const float *flows,
+                              const void *ref_proc, int ref_dtype, int T, int Z, int Y, int X, int C,
+                              int order, double *new_ref);
 
 /* Per-volume displacement statistics of the batch driver (SURVEY section 8 f-2;
  * motion_correction/compensate_recording_3D.py:488-508).  flows: (T,Z,Y,X,3) fp32;

@@ -285,8 +285,49 @@ static void spline_weights(double x, int order, double *wts)
 
 static int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
+/* Output conversion of the executor's final warp of a RAW volume (parallelization/sequential_3d.py:
+ * 153-170): scipy.ndimage.map_coordinates allocates its output in the INPUT's dtype, so the interpolated
+ * double is converted by NI_GeometricTransform's output cast (ni_interpolation.c CASE_INTERP_OUT_*:
+ * unsigned: t > 0 ? t + 0.5 : 0, clamped to the type's maximum, truncated; signed: t +- 0.5, clamped,
+ * truncated; float/double: plain cast), then stored into the float32 `warped` array
+ * (core/optical_flow_3d.py:59-66) and finally into `registered` of the batch's dtype.  Out-of-bounds
+ * voxels take f1 through float32 (:69-70) and NumPy's float -> integer cast (truncation).
+ * out_dtype: 0 f32, 1 f64, 2 u8, 3 u16, 4 i16. */
+static void store_typed(void *out, size_t idx, int out_dtype, double t, int interpolated)
+{
+    if (out_dtype == 0) { ((float *)out)[idx] = (float)t; return; }
+    if (out_dtype == 1) { ((double *)out)[idx] = (double)(float)t; return; }
+    if (!interpolated) {
+        float f = (float)t;  /* warped[...] = f1 (float32), then registered[t] = warped */
+        if (out_dtype == 2) ((unsigned char *)out)[idx] = (unsigned char)f;
+        else if (out_dtype == 3) ((unsigned short *)out)[idx] = (unsigned short)f;
+        else ((short *)out)[idx] = (short)f;
+        return;
+    }
+    if (out_dtype == 2 || out_dtype == 3) {
+        const double mx = out_dtype == 2 ? 255.0 : 65535.0;
+        t = t > 0 ? t + 0.5 : 0;
+        t = t > mx ? mx : t;
+        t = t < 0 ? 0 : t;
+        if (out_dtype == 2) ((unsigned char *)out)[idx] = (unsigned char)t;
+        else ((unsigned short *)out)[idx] = (unsigned short)t;
+    } else {
+        t = t > 0 ? t + 0.5 : t - 0.5;
+        t = t > 32767.0 ? 32767.0 : t;
+        t = t < -32768.0 ? -32768.0 : t;
+        ((short *)out)[idx] = (short)t;
+    }
+}
+
 void fr3d_oracle_imregister(const double *f2, const double *u, const double *v, const double *w,
                             const double *f1, int Z, int Y, int X, int C, int order, float *out)
+{
+    fr3d_oracle_imregister_typed(f2, u, v, w, f1, Z, Y, X, C, order, 0, out);
+}
+
+void fr3d_oracle_imregister_typed(const double *f2, const double *u, const double *v, const double *w,
+                                  const double *f1, int Z, int Y, int X, int C, int order, int out_dtype,
+                                  void *out)
 {
     const int npad = (order > 1) ? 12 : 0;
     const int PZ = Z + 2 * npad, PY = Y + 2 * npad, PX = X + 2 * npad;
@@ -316,7 +357,7 @@ void fr3d_oracle_imregister(const double *f2, const double *u, const double *v, 
                               (mz < 0.0f) || (mz >= (float)Z);
                     if (oob) {
                         /* :69-70 */
-                        out[i * C + c] = (float)f1[i * C + c];
+                        store_typed(out, i * C + c, out_dtype, f1[i * C + c], 0);
                         continue;
                     }
                     /* :47-49 np.clip in fp32 (in-bounds points are unchanged except > N-1) */
@@ -345,11 +386,44 @@ void fr3d_oracle_imregister(const double *f2, const double *u, const double *v, 
                             }
                         }
                     }
-                    out[i * C + c] = (float)t;
+                    store_typed(out, i * C + c, out_dtype, t, 1);
                 }
     }
     (void)nvox;
     free(coef);
+}
+
+/* f-4  BatchMotionCorrector._update_reference       motion_correction/compensate_recording_3D.py:395-429
+ * batch_proc (T,Z,Y,X,C) fp64, flows (T,Z,Y,X,3) fp32, ref_proc (Z,Y,X,C) fp64 -> new_ref (Z,Y,X,C) fp64.
+ * Per channel: the last n = min(100,T) volumes are warped one channel at a time by imregister_wrapper
+ * (fp32 result) into an fp64 stack whose mean over the stack axis is taken: np.mean(axis=0) on a
+ * C-contiguous (n,Z,Y,X) array adds the volumes in order t = 0..n-1 and divides the sum by n. */
+void fr3d_oracle_update_reference(const double *batch_proc, const float *flows, const double *ref_proc, int T,
+                                  int Z, int Y, int X, int C, int order, double *new_ref)
+{
+    const size_t nv = (size_t)Z * Y * X;
+    const int n_ref = T < 100 ? T : 100;
+    if (n_ref < 1) return;
+    const int start = T - n_ref;
+    double *vol = (double *)xmalloc(sizeof(double) * nv), *refc = (double *)xmalloc(sizeof(double) * nv);
+    double *u = (double *)xmalloc(sizeof(double) * nv), *v = (double *)xmalloc(sizeof(double) * nv),
+           *w = (double *)xmalloc(sizeof(double) * nv), *acc = (double *)xmalloc(sizeof(double) * nv);
+    float *out = (float *)xmalloc(sizeof(float) * nv);
+    for (int c = 0; c < C; c++) {
+        for (size_t q = 0; q < nv; q++) { refc[q] = ref_proc[q * C + c]; acc[q] = 0.0; }
+        for (int t = 0; t < n_ref; t++) {
+            const double *bp = batch_proc + (size_t)(start + t) * nv * C;
+            const float *fl = flows + (size_t)(start + t) * nv * 3;
+            for (size_t q = 0; q < nv; q++) {
+                vol[q] = bp[q * C + c];
+                u[q] = (double)fl[q * 3 + 0]; v[q] = (double)fl[q * 3 + 1]; w[q] = (double)fl[q * 3 + 2];
+            }
+            fr3d_oracle_imregister(vol, u, v, w, refc, Z, Y, X, 1, order, out);
+            for (size_t q = 0; q < nv; q++) acc[q] = (t == 0) ? (double)out[q] : acc[q] + (double)out[q];
+        }
+        for (size_t q = 0; q < nv; q++) new_ref[q * C + c] = acc[q] / (double)n_ref;
+    }
+    free(vol); free(refc); free(u); free(v); free(w); free(acc); free(out);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -39,6 +39,19 @@ void fr3d_oracle_spline_filter3(double *c, int Z, int Y, int X);
 void fr3d_oracle_imregister(const double *f2, const double *u, const double *v, const double *w,
                             const double *f1, int Z, int Y, int X, int C, int order, float *out);
 
+/* The same with the output stored as the executor's final warp stores it when the raw volume has dtype
+ * out_dtype (0 f32, 1 f64, 2 u8, 3 u16, 4 i16; SciPy allocates map_coordinates' output in the input's
+ * dtype): parallelization/sequential_3d.py:153-170.  f2 holds the raw values exactly (fp64). */
+void fr3d_oracle_imregister_typed(const double *f2, const double *u, const double *v, const double *w,
+                                  const double *f1, int Z, int Y, int X, int C, int order, int out_dtype,
+                                  void *out);
+
+/* BatchMotionCorrector._update_reference (motion_correction/compensate_recording_3D.py:395-429):
+ * batch_proc (T,Z,Y,X,C) fp64, flows (T,Z,Y,X,3) fp32, ref_proc (Z,Y,X,C) fp64 -> new_ref (Z,Y,X,C) fp64 =
+ * per-channel mean of the last min(100,T) volumes warped by their flows (order 3 cubic / 1 linear). */
+void fr3d_oracle_update_reference(const double *batch_proc, const float *flows, const double *ref_proc, int T,
+                                  int Z, int Y, int X, int C, int order, double *new_ref);
+
 /* core/optical_flow_3d.py:92-152.  f1,f2: (Z,Y,X) fp64.  J: 10 arrays (Z+2,Y+2,X+2) in the
  * reference's return order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 (outer ring zero). */
 void fr3d_oracle_motion_tensor_gc(const double *f1, const double *f2, int Z, int Y, int X,

@@ -123,6 +123,40 @@ def imregister_wrapper(f2_level, u, v, w, f1_level, interpolation_method="cubic"
     return out[..., 0] if Cn == 1 else out
 
 
+_RAW_CODES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3,
+              np.dtype(np.int16): 4}
+
+
+def register_raw(vol, flow, ref, interpolation_method="cubic"):
+    """registered[t] of the executors (parallelization/sequential_3d.py:153-170): imregister_wrapper on the RAW
+    volume `vol` (Z,Y,X,C) in its own dtype with the float32 flow, stored into an array of vol.dtype."""
+    vol = np.asarray(vol)
+    code = _RAW_CODES[vol.dtype]
+    order = 3 if interpolation_method.lower() == "cubic" else 1
+    Z, Y, X, Cn = vol.shape
+    f2d = np.ascontiguousarray(vol, dtype=np.float64)
+    f1d = np.ascontiguousarray(np.asarray(ref).reshape(Z, Y, X, Cn), dtype=np.float64)
+    fl = np.asarray(flow, dtype=np.float32)
+    ud, vd, wd = (np.ascontiguousarray(fl[..., d], dtype=np.float64) for d in range(3))
+    out = np.empty((Z, Y, X, Cn), vol.dtype)
+    lib().fr3d_oracle_imregister_typed(_d(f2d), _d(ud), _d(vd), _d(wd), _d(f1d), Z, Y, X, Cn, order, code,
+                                       out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def update_reference(batch_proc, w, reference_proc, interpolation_method="cubic"):
+    """BatchMotionCorrector._update_reference (motion_correction/compensate_recording_3D.py:395-429) -> new
+    reference_proc (Z,Y,X,C) float64."""
+    bp = np.ascontiguousarray(batch_proc, dtype=np.float64)
+    fl = np.ascontiguousarray(w, dtype=np.float32)
+    rp = np.ascontiguousarray(reference_proc, dtype=np.float64)
+    T, Z, Y, X, Cn = bp.shape
+    out = np.array(rp, copy=True)
+    order = 3 if interpolation_method.lower() == "cubic" else 1
+    lib().fr3d_oracle_update_reference(_d(bp), _f(fl), _d(rp), T, Z, Y, X, Cn, order, _d(out))
+    return out
+
+
 def get_motion_tensor_gc(f1, f2, hz, hy, hx):
     """core/optical_flow_3d.py:92 -> (J11,J22,J33,J44,J12,J13,J23,J14,J24,J34)"""
     f1d = np.ascontiguousarray(f1, dtype=np.float64)
