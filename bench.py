@@ -11,12 +11,17 @@ by torch.distributed.run, one rank per GPU) the series is sharded volume-per-GPU
 reference is broadcast once from rank 0 over RCCL and nothing else is exchanged ("scaling": weak).
 
 Prints ONE JSON line on rank 0 (schema in the task contract) with `roofline` for the SOR sweep
-kernel (HIP events on the engine's stream) and `cpu_baseline` (the C oracle on a bounded sample).
+kernel (HIP events on the engine's stream) and `cpu_baseline` (the C oracle on a bounded sample, one
+core and all cores).  At N = 1 the default run adds two legs to the same line, after the timed region of
+the headline workload: `host_path` (NumPy arrays in, NumPy arrays out through fr3d_process_batch: the
+PCIe-inclusive rate of the drop-in entry, never `value`) and `cfg3` (the 512^3 six-level configuration,
+4 timed steps at lock-step batch 4, with its own `roofline`); `--no-extras` skips both.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -70,87 +75,108 @@ class DevArray:
             self.ptr = None
 
 
-def cpu_baseline(workload, sample_edge):
-    """Time the CPU oracle (restatement of the reference's NumPy/Numba path) on one core on a
-    bounded cube of the same workload; scale to the workload's voxel count."""
+def _cpu_volume(args):
+    """one volume of the CPU path (flow solve + compensation warp) on one core; -> seconds"""
+    shape, levels = args
     from oracle import oracle
-    from flowreg3d_amd.synthetic import make_pair
-    Z, Y, X, levels, _ = WORKLOADS[workload]
-    e = min(sample_edge, Z, Y, X)
-    shape = (e, e, e) if workload != "cfg1" else (Z, Y, X)
-    fixed, moving, _ = make_pair(shape, seed=1234, cheap=True)
+    from flowreg3d_amd.synthetic import fast_pair
+    fixed, moving, _ = fast_pair(shape)
     kw = solver_kwargs(levels)
     t0 = time.perf_counter()
     flow = oracle.get_displacement(fixed, moving, **kw).astype(np.float32)
     oracle.imregister_wrapper(moving, flow[..., 0], flow[..., 1], flow[..., 2], fixed)
-    dt = time.perf_counter() - t0
+    return time.perf_counter() - t0
+
+
+def _cpu_share():
+    """CPU cores this process may really use: affinity mask, cgroup quota, FR3D_CPU_WORKERS; at most 16
+    worker processes unless told otherwise (the CPU share of a one-GPU box of the pool)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("FR3D_CPU_WORKERS")
+    return max(1, int(env)) if env else min(n, 16)
+
+
+def cpu_baseline(workload, sample_edge):
+    """The CPU oracle (restatement of the reference's NumPy/Numba path; kind "port") timed on this host:
+    one volume on one core, then one volume per core on every core at once (one process per volume,
+    as the reference's MultiprocessingExecutor3D runs it, parallelization/multiprocessing_3d.py:309-318).
+    The sample is a cube of `sample_edge` voxels with the workload's pyramid and solver parameters (the
+    oracle needs 3.5-7 minutes for one 256^3 volume, tests/golden/fullsize_cfg2.npz metadata); `value`
+    scales the all-core sample rate to the workload's voxel count."""
+    from oracle import oracle
+    oracle.build()
+    Z, Y, X, levels, _ = WORKLOADS[workload]
+    e = min(sample_edge, Z, Y, X)
+    shape = (e, e, e) if workload != "cfg1" else (Z, Y, X)
     scale = (shape[0] * shape[1] * shape[2]) / float(Z * Y * X)
-    return {"value": scale / dt, "unit": "volumes/sec", "cores": 1, "kind": "port",
-            "sample": f"{shape[0]}x{shape[1]}x{shape[2]} pair, same pyramid/solver parameters, "
-                      f"{dt:.1f} s on 1 core; scaled by voxel count to {Z}x{Y}x{X}"}
+    t1 = _cpu_volume((shape, levels))
+    cores = _cpu_share()
+    # memory: the oracle holds ~300 B per voxel of the finest level; keep the concurrent volumes inside half the RAM
+    try:
+        ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+        cores = max(1, min(cores, int(0.5 * ram / (320.0 * shape[0] * shape[1] * shape[2]))))
+    except (ValueError, OSError):
+        pass
+    # one child interpreter per volume (started before this process touches the GPU, see main()); each prints
+    # the seconds its volume took
+    code = f"import bench; print(bench._cpu_volume((({shape[0]}, {shape[1]}, {shape[2]}), {levels})))"
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, text=True)
+             for _ in range(cores)]
+    per = []
+    for pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("CPU baseline worker failed")
+        per.append(float(out.strip().splitlines()[-1]))
+    t_all = time.perf_counter() - t0
+    rate_all = cores / t_all
+    return {"value": rate_all * scale, "unit": "volumes/sec", "cores": cores, "kind": "port",
+            "sample": f"{shape[0]}x{shape[1]}x{shape[2]} pair, same pyramid/solver parameters: 1 volume on 1 core {t1:.1f} s; "
+                      f"{cores} volumes on {cores} cores (one process per volume) {t_all:.1f} s wall, "
+                      f"{min(per):.1f}-{max(per):.1f} s each; rates scaled by voxel count to {Z}x{Y}x{X}",
+            "value_1core": scale / t1, "sample_volumes_per_sec_1core": 1.0 / t1,
+            "sample_volumes_per_sec_all_cores": rate_all, "host_cpus": os.cpu_count()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=80, help="edge of the CPU-baseline cube")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solver-fp64", type=int, default=1, choices=(0, 1, 2),
-                    help="0 fp32 storage+update, 1 fp32 storage with fp64 update arithmetic (default = the library's "
-                         "choice for one channel; same speed as 0), 2 fp64 storage (parity-grade, 2x the bytes)")
-    ap.add_argument("--batch", type=int, default=0,
-                    help="volumes solved in lock step per GPU (shared launches); 0 = 8, or 4 at 512^3 "
-                         "where 8 slabs of solver operands (43 GB each) would not fit in 288 GB")
-    ap.add_argument("--condition", type=float, default=30.0,
-                    help="seconds of untimed warm-up work before the timed steps (0 = only the W warm-up steps)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    dev_index = local_rank
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        # "nccl" is RCCL on ROCm.  FR3D_DIST_BACKEND=gloo lets the N>1 path be rehearsed on a
-        # one-GPU box (ranks then share device 0); it is never used for reported numbers.
-        backend = os.environ.get("FR3D_DIST_BACKEND", "nccl")
-        dev_index = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(dev_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-
-    from flowreg3d_amd import _lib
-    from flowreg3d_amd.synthetic import flow_gt, texture
-    lib = _lib.init(dev_index)
-
-    Z, Y, X, levels, desc = WORKLOADS[args.workload]
+def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, world, dist, dev_index, fast_inputs):
+    """Warm up, condition, time EXACTLY K steps (volumes per rank) of `workload`; -> dict of results.
+    Inputs are generated once and are resident in HBM before the timed region starts."""
+    from flowreg3d_amd.synthetic import fast_pair, flow_gt, texture
+    Z, Y, X, levels, desc = WORKLOADS[workload]
     nv = Z * Y * X
-    K, W = args.steps, args.warmup
     T = K + W
-    kw = solver_kwargs(levels)
-    params = _lib.make_params(n_channels=1, solver_fp64=args.solver_fp64, **kw)
+    params = _lib.make_params(n_channels=1, solver_fp64=solver_fp64, **solver_kwargs(levels))
+
+    def reference_volume():
+        # texture(): blurred noise + blobs (SURVEY 8d); fast_pair's O(N) stand-in where the 512^3 blur would
+        # cost a minute of host time inside the default run
+        return fast_pair((Z, Y, X))[0] if fast_inputs else texture((Z, Y, X), seed=1234)
 
     # ---- fixed reference: generated on rank 0, broadcast over RCCL/xGMI -----------------------
     ref_dev = DevArray(lib, (Z, Y, X, 1))
+    ref_t = None
     if world > 1:
         import torch
         ref_t = torch.empty((Z, Y, X), dtype=torch.float32, device=f"cuda:{dev_index}")
         if rank == 0:
-            ref_t.copy_(torch.from_numpy(texture((Z, Y, X), seed=1234)))
+            ref_t.copy_(torch.from_numpy(reference_volume()))
         dist.broadcast(ref_t, src=0)  # the path's only collective
         torch.cuda.synchronize()
         fixed_ptr = ref_t.data_ptr()
     else:
-        ref_dev.upload(texture((Z, Y, X), seed=1234))
+        ref_dev.upload(reference_volume())
         fixed_ptr = ref_dev.ptr
 
     # ---- this rank's shard of the time series: moving_t = warp(fixed, -flow_gt * s_t) on the GPU --
@@ -166,7 +192,7 @@ def main():
                                      batch.ptr + i * nv * 4))
     gflow.free()
 
-    batch_vols = max(1, min(K, args.batch if args.batch > 0 else (4 if args.workload == "cfg3" else 8)))
+    batch_vols = max(1, min(K, batch_arg if batch_arg > 0 else (4 if workload == "cfg3" else 8)))
     lib.fr3d_set_batch(batch_vols)  # warm-up and timed run use the same lock-step batch / workspace
 
     def run(first, count, prof):
@@ -195,7 +221,7 @@ def main():
         # whatever the binary): keep repeating the warm-up batch, untimed, for --condition seconds
         # so that the timed steps see the steady state a long series runs in.
         t_c = time.perf_counter()
-        while args.condition > 0 and time.perf_counter() - t_c < args.condition:
+        while condition > 0 and time.perf_counter() - t_c < condition:
             run(0, max(W, batch_vols), False)
             lib.fr3d_sync()
     barrier()
@@ -210,26 +236,134 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-
+    res = {"elapsed": elapsed, "stats": stats, "batch_vols": batch_vols, "desc": desc}
     if rank == 0:
         sor = stats["sor"]
-        # HBM traffic of the SOR kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 per
-        # the gfx950 correction, + WRITE_SIZE; tools/gpu_measure.sh), stored per voxel update
-        traffic = None
+        achieved = sor["algo_bytes"] / (sor["ms"] * 1e-3) / 1e9 if sor["ms"] > 0 else 0.0
+        # HBM traffic of the SOR kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
+        # correction + WRITE_SIZE), stored per voxel update in profiles/pmc_traffic.json by
+        # tools/make_pmc_traffic.py -- a constant of the committed kernel, NOT measured by this run
+        traffic, traffic_source = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                pmc = json.load(fh).get(args.workload)
+                pj = json.load(fh)
+            pmc = pj.get(workload)
             if pmc:
                 traffic = pmc["bytes_per_update"] * sor["units"] / max(sor["launches"], 1)
+                traffic_source = f"profiles/pmc_traffic.json ({pj.get('_taken_at', 'round 1, commit 0249743')}): " \
+                                 f"{pmc['bytes_per_update']:.1f} B per voxel update x this run's updates per launch"
         except (OSError, ValueError, KeyError):
             traffic = None
-        achieved = sor["algo_bytes"] / (sor["ms"] * 1e-3) / 1e9 if sor["ms"] > 0 else 0.0
+        res["roofline"] = {"bound": "hbm", "kernel": "k_sor_step (SOR hyperplane sweep)",
+                           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                           "algo_bytes_per_launch": sor["algo_bytes"] / max(sor["launches"], 1),
+                           "avg_launch_us": 1e3 * sor["ms"] / max(sor["launches"], 1),
+                           "launches": sor["launches"]}
+        res["kernel_ms_per_step"] = {k: round(v["ms"] / K, 3) for k, v in stats.items()}
+        # the other stages of the path against the same HBM roofline, algorithmic bytes as in
+        # DESIGN.md section 5 (warp: 24 B/voxel; the median is compute-bound and listed for completeness)
+        res["roofline_stages"] = {k: {"achieved": round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                      "frac": round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                  for k, v in stats.items()
+                                  if k in ("warp", "prefilter", "tensor", "resize", "median") and v["ms"] > 0}
+    for a in (batch, flows, regs, ref_dev):
+        a.free()
+    del ref_t
+    return res
+
+
+def host_path(workload, n_vol, solver_fp64):
+    """The drop-in entry as the reference calls it: NumPy arrays in, NumPy arrays out through
+    HipExecutor3D.process_batch -> fr3d_process_batch_raw (pageable host memory, PCIe both ways)."""
+    from flowreg3d_amd.executor import HipExecutor3D
+    from flowreg3d_amd.synthetic import fast_pair
+    Z, Y, X, levels, _ = WORKLOADS[workload]
+    fixed, moving, _ = fast_pair((Z, Y, X))
+    batch = np.ascontiguousarray(np.stack([moving] * n_vol)[..., None])
+    fp = dict(solver_kwargs(levels), weight=np.array([1.0]), solver_fp64=solver_fp64)
+    w0 = np.zeros((Z, Y, X, 3), np.float32)
+    ref = fixed[..., None]
+    best = None
+    with HipExecutor3D() as ex:
+        for _ in range(2):  # first call allocates staging buffers and faults in the output arrays
+            t0 = time.perf_counter()
+            reg, flows = ex.process_batch(batch, batch, ref, ref, w0, None, None, flow_params=fp)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    return {"value": n_vol / best, "unit": "volumes/sec", "volumes": n_vol,
+            "what": f"{workload}: HipExecutor3D.process_batch on NumPy arrays ({batch.nbytes >> 20} MiB in x2, "
+                    f"{(reg.nbytes + flows.nbytes) >> 20} MiB out, pageable memory), second of two calls"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=128, help="edge of the CPU-baseline cube")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra legs of the default run (host-array path, the 512^3 line)")
+    ap.add_argument("--solver-fp64", type=int, default=1, choices=(0, 1, 2),
+                    help="0 fp32 storage+update, 1 fp32 storage with fp64 update arithmetic (default = the library's "
+                         "choice for one channel; same speed as 0), 2 fp64 storage (parity-grade, 2x the bytes)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="volumes solved in lock step per GPU (shared launches); 0 = 8, or 4 at 512^3 "
+                         "where 8 slabs of solver operands (43 GB each) would not fit in 288 GB")
+    ap.add_argument("--condition", type=float, default=30.0,
+                    help="seconds of untimed warm-up work before the timed steps (0 = only the W warm-up steps)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # The CPU baseline runs FIRST, before this process touches the GPU: its all-core leg starts one worker
+    # process per core, and a process that has initialised HIP must not spawn/exec (rank 0 at N = 1 only).
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, args.cpu_sample)
+
+    dist = None
+    dev_index = local_rank
+    backend = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        # "nccl" is RCCL on ROCm.  FR3D_DIST_BACKEND=gloo lets the N>1 path be rehearsed on a
+        # one-GPU box (ranks then share device 0); it is never used for reported numbers.
+        backend = os.environ.get("FR3D_DIST_BACKEND", "nccl")
+        dev_index = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+        world = dist.get_world_size()
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from flowreg3d_amd import _lib
+    lib = _lib.init(dev_index)
+    K, W = args.steps, args.warmup
+    m = measure(lib, _lib, args.workload, K, W, args.batch, args.condition, args.solver_fp64, rank, world, dist,
+                dev_index, fast_inputs=False)
+
+    if rank == 0:
+        elapsed = m["elapsed"]
+        achieved = m["roofline"]["achieved"]
         # what a plain y += x stream reaches on this device right now (1 GiB arrays, after the timed
         # steps): the practical ceiling behind the nominal 8 TB/s
         stream = C.c_double(0.0)
         _lib.check(lib.fr3d_stream_probe(1 << 28, 20, C.byref(stream)))
         rstream = C.c_double(0.0)  # read-only stream (the sweep's real traffic is 83 % reads)
         _lib.check(lib.fr3d_read_probe(1 << 26, 20, C.byref(rstream)))
+        m["roofline"].update(stream_measured=round(stream.value, 1), read_stream_measured=round(rstream.value, 1),
+                             frac_of_stream_measured=round(achieved / stream.value, 4) if stream.value > 0 else None)
+        solver_names = ("fp32 storage, fp32 update arithmetic", "fp32 storage, fp64 update arithmetic",
+                        "fp64 storage and arithmetic")
         out = {
             "metric": "volumes/sec (3D flow solve + warp)",
             "value": (K * world) / elapsed,
@@ -243,33 +377,34 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.solver_fp64 < 2 else "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}; iterations=100, update_lag=5, eta=0.8, "
+            "config": {"workload": f"{args.workload}: {m['desc']}; iterations=100, update_lag=5, eta=0.8, "
                                    "alpha=0.25, a_data=0.45, a_smooth=1; lexicographic-exact SOR",
-                       "solver": ("fp32 storage, fp32 update arithmetic", "fp32 storage, fp64 update arithmetic",
-                                  "fp64 storage and arithmetic")[args.solver_fp64],
-                       "volumes_per_gpu_per_step": 1, "lockstep_batch": batch_vols,
+                       "solver": solver_names[args.solver_fp64],
+                       "volumes_per_gpu_per_step": 1, "lockstep_batch": m["batch_vols"],
                        "untimed_conditioning_s": args.condition if W > 0 else 0.0,
                        "sharding": f"volume-per-GPU x{world}",
+                       "world_size": world, "dist_backend": backend if world > 1 else "none (single process)",
+                       "collectives": "one broadcast of the fixed reference (+ the timing all-reduce)" if world > 1 else "none",
                        "device": lib.fr3d_device_info().decode()},
-            "roofline": {"bound": "hbm", "kernel": "k_sor_step (SOR hyperplane sweep)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algo_bytes_per_launch": sor["algo_bytes"] / max(sor["launches"], 1),
-                         "avg_launch_us": 1e3 * sor["ms"] / max(sor["launches"], 1),
-                         "launches": sor["launches"],
-                         "stream_measured": round(stream.value, 1),
-                         "read_stream_measured": round(rstream.value, 1),
-                         "frac_of_stream_measured": round(achieved / stream.value, 4) if stream.value > 0 else None},
-            "kernel_ms_per_step": {k: round(v["ms"] / K, 3) for k, v in stats.items()},
-            # the other stages of the path against the same HBM roofline, algorithmic bytes as in
-            # DESIGN.md section 5 (warp: 24 B/voxel; the median is compute-bound and listed for completeness)
-            "roofline_stages": {k: {"achieved": round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                    "frac": round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                                for k, v in stats.items()
-                                if k in ("warp", "prefilter", "tensor", "resize", "median") and v["ms"] > 0},
+            "roofline": m["roofline"],
+            "kernel_ms_per_step": m["kernel_ms_per_step"],
+            "roofline_stages": m["roofline_stages"],
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
+        if world == 1 and not args.no_extras and args.workload == "cfg2":
+            # (1) the host-array entry (PCIe both ways) -- reported beside `value`, never as `value`
+            out["host_path"] = host_path("cfg2", 8, args.solver_fp64)
+            # (2) the 512^3 configuration the roofline target is stated on: workspace of the 256^3 run is
+            # released first (8 slabs of 5.4 GB + 4 slabs of 43 GB would not fit next to each other)
+            _lib.shutdown()
+            lib = _lib.init(dev_index)
+            c3 = measure(lib, _lib, "cfg3", 4, 1, 4, 8.0, args.solver_fp64, 0, 1, None, dev_index, fast_inputs=True)
+            out["cfg3"] = {"workload": f"cfg3: {c3['desc']}; same solver parameters", "value": 4 / c3["elapsed"],
+                           "unit": "volumes/sec", "steps": 4, "warmup": 1, "ms_per_step": 1e3 * c3["elapsed"] / 4,
+                           "lockstep_batch": c3["batch_vols"], "untimed_conditioning_s": 8.0,
+                           "solver": solver_names[args.solver_fp64], "roofline": c3["roofline"],
+                           "kernel_ms_per_step": c3["kernel_ms_per_step"], "roofline_stages": c3["roofline_stages"]}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -83,6 +83,7 @@ SIGNATURES = {
                                         C.c_int, _dp]),
     "fr3d_update_reference_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int, _dp]),
+    "fr3d_mean_stack_dev": (C.c_int, [_vp, C.c_int, C.c_size_t, _vp]),
     "fr3d_flow_stats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "fr3d_flow_stats_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "fr3d_resize3d": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

@@ -218,14 +218,6 @@ struct Engine {
     std::map<std::string, DevBuf> bufs;
     std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
     std::map<std::tuple<int, int, int, int, int>, SorSched> scheds;  // (Z,Y,X,iterations,lag) of a level
-    // pair-sweep schedules (k_sor_pair.hip): keyed (Z,Y,X,iterations,-rows)
-    const SorSched &pair_sched(const Skew &sk, int iterations, int rows)
-    {
-        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, -rows);
-        auto it = scheds.find(key);
-        if (it == scheds.end()) it = scheds.emplace(key, build_sor_pair_schedule(sk, iterations, rows)).first;
-        return it->second;
-    }
 
     const SorSched &sched(const Skew &sk, int iterations, int lag = 2)
     {
@@ -508,18 +500,9 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         }
         a.iterations = p.iterations;
         a.update_lag = p.update_lag;
-        S *dres = dbuf;  // where the increments end up
         if (p.a_smooth == 1.0) {
-            const int pair_rows = sor_kernel_choice(sk);
-            if (pair_rows) {  // two hyperplanes per launch: increments double-buffered by iteration parity
-                S *dbuf2 = (S *)e.bufs["d2_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
-                FR3D_HIP(hipMemsetAsync(dbuf2, 0, ns * 3 * nb * sizeof(S), e.st));
-                for (int d = 0; d < 3; d++) a.dB[d] = dbuf2 + (size_t)d * ns;
-                if (sor_pair_result(p.iterations)) dres = dbuf2;
-            }
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
-            long long n = pair_rows ? launch_sor_pair<S>(e.st, a, p.solver_fp64 != 0, e.pair_sched(sk, p.iterations, pair_rows))
-                                    : launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
+            long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
             sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
         } else {
             // a_smooth != 1 (k_sor_smooth.hip): psi_smooth every iteration, triple-buffered increments,
@@ -569,7 +552,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 Span sp(e, FR3D_K_OTHER, 0, 0, 0);
                 // increments leave the solver rounded to fp32: the next level (and the executor) cast to
                 // fp32 anyway (util/resize_util_3D.py:116, sequential_3d.py:150) and the median commutes with it
-                launch_unskew_copy_n<S, float>(e.st, dres + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
+                launch_unskew_copy_n<S, float>(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
             }
             if (med) {
                 Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);
@@ -638,8 +621,8 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
     const Level &F = lv.back();
     const Skew sk = make_skew(F.z, F.y, F.x);
     const double nfin = (double)F.z * F.y * F.x;
-    // skewed solver slabs (factors, system, L, two increment buffers) + the level flows of a volume (two generations of u,v,w)
-    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 9.0) + nfin * 4.0 * 9.0;
+    // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
+    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0) + nfin * 4.0 * 9.0;
     // volume-independent scratch of the finest level: tensor/Laplacian staging (15), moving level and
     // its warp (2C), fp64 spline coefficients on the padded grid (~2.5), increments and flow (9),
     // reference and weight pyramids (~4C)
@@ -662,9 +645,9 @@ static void check_params(const fr3d_params *p, int Z, int Y, int X, int C)
 {
     FR3D_CHECK(p != nullptr, "params is NULL");
     FR3D_CHECK(Z >= 1 && Y >= 1 && X >= 1, "volume dimensions must be >= 1");
-    FR3D_CHECK(C >= 1 && C <= 4, "1..4 channels are supported");
+    FR3D_CHECK(C >= 1 && C <= FR3D_MAX_CHANNELS, "1..8 channels are supported (FR3D_MAX_CHANNELS)");
     FR3D_CHECK(p->iterations >= 0 && p->update_lag >= 1, "iterations >= 0 and update_lag >= 1 required");
-    FR3D_CHECK(p->eta > 0.0 && p->eta < 1.0, "eta must be in (0,1)");
+    FR3D_CHECK(p->eta > 0.0 && p->eta <= 1.0, "eta must be in (0,1]");  // eta == 1: `levels` solves at full size, like the reference
     FR3D_CHECK(p->levels >= 1, "levels must be >= 1");
 }
 
@@ -1305,6 +1288,16 @@ int fr3d_update_reference(const void *batch_proc, int proc_dtype, const float *f
     FR3D_CATCH
 }
 
+int fr3d_mean_stack_dev(const float *stack, int count, size_t n, float *out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(stack && out && count >= 1, "bad mean_stack arguments");
+    launch_mean_stack_f32(g_eng.st, stack, count, (long long)n, out);
+    FR3D_HIP(hipStreamSynchronize(g_eng.st));
+    FR3D_CATCH
+}
+
 int fr3d_preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *norm_min,
                         const double *norm_den, const double *sigma, double truncate, void *out, int out_dtype)
 {
@@ -1417,7 +1410,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     FR3D_TRY
     ensure_init();
     FR3D_CHECK(A && weight && uvw && alpha3 && a_data && duvw_out, "NULL pointer");
-    FR3D_CHECK(Z > 0 && Y > 0 && X > 0 && C >= 1 && C <= 4, "bad solver shape");
+    FR3D_CHECK(Z > 0 && Y > 0 && X > 0 && C >= 1 && C <= FR3D_MAX_CHANNELS, "bad solver shape");
     FR3D_CHECK(iterations >= 0 && update_lag >= 1, "iterations >= 0 and update_lag >= 1 required");
     Engine &e = g_eng;
     const size_t n = (size_t)Z * Y * X;
@@ -1460,18 +1453,8 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     FR3D_HIP(hipMemsetAsync(db, 0, ns * 3 * 4, e.st));
     a.iterations = iterations;
     a.update_lag = update_lag;
-    float *dres = db;
     if (a_smooth == 1.0) {
-        const int pair_rows = sor_kernel_choice(sk);
-        if (pair_rows) {
-            float *db2 = (float *)s.alloc(ns * 3 * 4);
-            FR3D_HIP(hipMemsetAsync(db2, 0, ns * 3 * 4, e.st));
-            for (int d = 0; d < 3; d++) a.dB[d] = db2 + (size_t)d * ns;
-            if (sor_pair_result(iterations)) dres = db2;
-            launch_sor_pair<float>(e.st, a, solver_fp64 != 0, e.pair_sched(sk, iterations, pair_rows));
-        } else {
-            launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
-        }
+        launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
     } else {
         float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);
         SmoothArgs<float> sa;
@@ -1497,7 +1480,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
         if (iterations > 0)
             FR3D_HIP(hipMemcpyAsync(db, sa.D[(iterations - 1) % 3][0], ns * 3 * 4, hipMemcpyDeviceToDevice, e.st));
     }
-    launch_unskew_copy_n<float, float>(e.st, dres, (long long)ns, dn, (long long)n, 3, sk);
+    launch_unskew_copy_n<float, float>(e.st, db, (long long)ns, dn, (long long)n, 3, sk);
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 4, hipMemcpyDeviceToHost));
     FR3D_CATCH
@@ -1522,7 +1505,7 @@ int fr3d_schedule(int Z, int Y, int X, double eta, int levels, int min_level, in
                   int *min_level_eff)
 {
     try {
-        if (Z < 1 || Y < 1 || X < 1 || !(eta > 0.0 && eta < 1.0) || levels < 1) {
+        if (Z < 1 || Y < 1 || X < 1 || !(eta > 0.0 && eta <= 1.0) || levels < 1) {
             g_err = "bad schedule arguments";
             return -1;
         }

@@ -89,8 +89,7 @@ struct SorArgsT {
     const S *A[12 * FR3D_MAX_CHANNELS];
     const S *weight[FR3D_MAX_CHANNELS];
     const S *L[3];  // alpha-weighted Laplacian of u,v,w (constant over the iterations)
-    S *d[3];        // du,dv,dw: updated in place by k_sor_step; buffer of the even iterations of k_sor_pair
-    S *dB[3];       // k_sor_pair only: buffer of the odd iterations (increments double-buffered by parity)
+    S *d[3];        // du,dv,dw, updated in place
     Skew sk;
     double ax, ay, az;  // alpha/h^2
     double a_data[FR3D_MAX_CHANNELS];
@@ -101,7 +100,6 @@ struct SorArgsT {
     int nvol;
     long long vsM, vsA, vsL, vsD;
     int dbg;  // measurement-only ablation bits (FR3D_SOR_DBG); 0 in production
-    int t_base;  // iteration number of the schedule's iteration 0 (windowed sweeps, see launch_sor)
 };
 using SorArgs = SorArgsT<float>;
 
@@ -210,20 +208,10 @@ int sor_tile_rows(const Skew &sk);
 // iteration t works on hyperplane tau - lag*t in launch tau (lag 2: a_smooth == 1 kernel; lag 4 = SM_LAG:
 // the a_smooth != 1 kernels, whose P-stage and sweep share one schedule two launches apart)
 SorSched build_sor_schedule(const Skew &sk, int iterations, int by, int lag = 2);
-// two hyperplanes per launch (k_sor_pair.hip): tiles of `rows` (6 or 14) rows x 64 lanes, lag 3
-SorSched build_sor_pair_schedule(const Skew &sk, int iterations, int rows);
 void free_sor_schedule(SorSched &s);
 // Runs all `iterations` pipelined hyperplane steps.  Returns the number of kernel launches.
 template <typename S>
 long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorSched &sched);
-
-// Pair sweep: needs a.dB; the final increments are in a.d when `iterations` is odd... see sor_pair_result().
-template <typename S>
-long long launch_sor_pair(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorSched &sched);
-// which buffer holds the increments after `iterations` pair-sweep iterations: 0 = a.d, 1 = a.dB
-static inline int sor_pair_result(int iterations) { return iterations > 0 ? ((iterations - 1) & 1) : 0; }
-// 0: k_sor_step (one hyperplane per launch), 6 / 14: k_sor_pair with that many rows per tile
-int sor_kernel_choice(const Skew &sk);
 
 // K8 median (natural layout)
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);
@@ -241,6 +229,9 @@ void launch_flow_stats(hipStream_t st, const float *flow, int Z, int Y, int X, i
 // f-4 update_reference: acc = first ? x : acc + x (fp64), out[t*C+c] = acc[t] / count
 void launch_accum_f64(hipStream_t st, double *acc, const float *x, long long n, bool first);
 void launch_mean_store(hipStream_t st, const double *acc, long long n, int C, int c, double count, double *out);
+
+// np.mean(axis=0) of a float32 stack of `count` arrays of n elements (float32 accumulation in stack order)
+void launch_mean_stack_f32(hipStream_t st, const float *stack, int count, long long n, float *out);
 
 // K9 pointwise helpers
 void launch_axpy(hipStream_t st, float *y, const float *x, long long n);  // y += x

@@ -65,6 +65,24 @@ k_mean_store(const double *__restrict__ acc, long long n, int C, int c, double c
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n) out[(size_t)t * C + c] = acc[t] / count;
 }
+// np.mean(stack, axis=0) of a float32 stack (count, n) as NumPy evaluates it: the volumes are added in
+// stack order in float32, the sum is divided by float32(count) (the rolling w_init of the batch driver,
+// compensate_recording_3D.py:481-485 and :342-393)
+__global__ void __launch_bounds__(256)
+k_mean_stack_f32(const float *__restrict__ stack, int count, long long n, float *__restrict__ out)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float acc = stack[t];
+    for (int q = 1; q < count; q++) acc = acc + stack[(size_t)q * n + t];
+    out[t] = acc / (float)count;
+}
+void launch_mean_stack_f32(hipStream_t st, const float *stack, int count, long long n, float *out)
+{
+    if (n > 0 && count > 0) hipLaunchKernelGGL(k_mean_stack_f32, dim3(cdiv(n, 256)), dim3(256), 0, st, stack, count, n, out);
+    FR3D_LAUNCH_CHECK();
+}
+
 void launch_accum_f64(hipStream_t st, double *acc, const float *x, long long n, bool first)
 {
     if (n > 0) hipLaunchKernelGGL(k_accum_f64, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, x, n, first ? 1 : 0);

@@ -23,7 +23,6 @@
 // the u,v,w part of the stencil is iteration-invariant and precomputed once (k_laplace).
 #include <algorithm>
 #include <cstdlib>
-#include <cstring>
 
 #include "fr3d_internal.h"
 #include "k_sor_core.h"
@@ -85,7 +84,7 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
     const R su_z = (R)ldb(dU, zm) + (R)ldb(dU, zp), sv_z = (R)ldb(dV, zm) + (R)ldb(dV, zp),
             sw_z = (R)ldb(dW, zm) + (R)ldb(dW, zp);
     R m[9];
-    const bool upd = ((a.t_base + t) % a.update_lag) == 0 && !(a.dbg & 4);
+    const bool upd = (t % a.update_lag) == 0 && !(a.dbg & 4);
     sor_system<R, S, C, I>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
     R du1, dv1, dw1;
     sor_relax<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,
@@ -113,23 +112,16 @@ static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo,
         FR3D_SOR_CASE(2)
         FR3D_SOR_CASE(3)
         FR3D_SOR_CASE(4)
-        default: throw Error("SOR kernel is instantiated for 1..4 channels");
+        // 5..FR3D_MAX_CHANNELS channels: one instantiation with the channel loop bound read at run time
+        // (the loop already handles one channel at a time, k_sor_core.h; level_solver_3d.py:356-377 loops over any C)
+        default:
+            FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
+            if (narrow) hipLaunchKernelGGL((k_sor_step<R, S, 0, unsigned>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut);
+            else hipLaunchKernelGGL((k_sor_step<R, S, 0, size_t>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut);
+            break;
     }
 #undef FR3D_SOR_CASE
-}
-
-int sor_kernel_choice(const Skew &sk)
-{
-    // FR3D_SOR_KERNEL: "step" = one hyperplane per launch (k_sor_step), "pair6"/"pair14" = two hyperplanes
-    // per launch with 6 or 14 rows per tile (k_sor_pair.hip).  Results are bit-identical.
-    const char *env = getenv("FR3D_SOR_KERNEL");
-    (void)sk;
-    if (env) {
-        if (!strcmp(env, "step")) return 0;
-        if (!strcmp(env, "pair6")) return 6;
-        if (!strcmp(env, "pair14")) return 14;
-    }
-    return 0;
+    FR3D_LAUNCH_CHECK();
 }
 
 int sor_tile_rows(const Skew &sk)

@@ -41,8 +41,9 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
         R M11 = 0, M22 = 0, M33 = 0, M12 = 0, M13 = 0, M23 = 0, bu = 0, bv = 0, bw = 0;
         // one channel at a time: unrolling over channels keeps 12C factors live and costs the ordinary
         // iterations (4 of 5) their occupancy
+        const int nch = C > 0 ? C : a.C;  // C == 0: channel count at run time (5..FR3D_MAX_CHANNELS channels)
 #pragma unroll 1
-        for (int c = 0; c < C; c++) {
+        for (int c = 0; c < nch; c++) {
             // psi_data update (level_solver_3d.py:356-377) from the increments of iteration t-1.
             // The quadratic form is evaluated as the sum of three squared residuals of the tensor's
             // square-root factors (see k_tensor.hip) -- algebraically the reference's expression,

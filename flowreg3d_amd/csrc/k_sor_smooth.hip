@@ -259,8 +259,9 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
     double M11, M22, M33, M12, M13, M23, bu, bv, bw;
     if ((t % a.update_lag) == 0) {
         M11 = M22 = M33 = M12 = M13 = M23 = bu = bv = bw = 0.0;
+        const int nch = C > 0 ? C : a.C;  // C == 0: channel count at run time (more than 4 channels)
 #pragma unroll
-        for (int c = 0; c < C; c++) {
+        for (int c = 0; c < nch; c++) {
             double f[12];
 #pragma unroll
             for (int q = 0; q < 12; q++) f[q] = (double)a.A[q * FR3D_MAX_CHANNELS + c][c0];
@@ -369,8 +370,12 @@ long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSch
             case 2: hipLaunchKernelGGL((k_smooth_step<S, 2>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
             case 3: hipLaunchKernelGGL((k_smooth_step<S, 3>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
             case 4: hipLaunchKernelGGL((k_smooth_step<S, 4>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
-            default: throw Error("SOR kernel is instantiated for 1..4 channels");
+            default:
+                FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
+                hipLaunchKernelGGL((k_smooth_step<S, 0>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj);
+                break;
         }
+        FR3D_LAUNCH_CHECK();
         launches++;
     }
     return launches;

@@ -185,3 +185,60 @@ class HipExecutor3D:
         if not direct:
             registered[...] = reg_dev
         return registered, flows
+
+    # -- sharded series: reference payload already in HBM (flowreg3d_amd/distributed.py) -------------------
+    def process_batch_device_refs(self, batch: np.ndarray, batch_proc: np.ndarray, ref_ptrs: Dict[str, Optional[int]],
+                                  ref_shape: Tuple[int, int, int, int], interpolation_method: str = "cubic",
+                                  progress_callback: Optional[Callable[[int], None]] = None, flow_params=None
+                                  ) -> Tuple[np.ndarray, np.ndarray]:
+        """``process_batch`` with reference_raw / reference_proc / w_init / weight given as DEVICE addresses of
+        float32 arrays (the fields of the broadcast buffer): only this rank's volumes cross PCIe."""
+        from .device import DeviceBuffer
+        T, Z, Y, X, nc = batch.shape
+        if (Z, Y, X, nc) != tuple(ref_shape):
+            raise ValueError(f"batch volumes {(Z, Y, X, nc)} do not match the reference {tuple(ref_shape)}")
+        order = _order_of(interpolation_method)
+        fp = {k: v for k, v in dict(flow_params or {}).items() if k not in ("cc_initialization", "cc_hw", "cc_up", "weight")}
+        params = _lib.make_params(fp.get("alpha", (2, 2, 2)), fp.get("update_lag", 10), fp.get("iterations", 20),
+                                  fp.get("min_level", 0), fp.get("levels", 50), fp.get("eta", 0.8),
+                                  float(fp.get("a_smooth", 0.5)), fp.get("a_data", 0.45), nc,
+                                  None if fp.get("solver_fp64") is None else int(fp["solver_fp64"]))
+        raw_code = _RAW_CODES.get(batch.dtype)
+        br = np.ascontiguousarray(batch if raw_code is not None else batch.astype(np.float64))
+        code = raw_code if raw_code is not None else _lib.F64
+        lib = self._lib or _lib.init(self.device)
+        bufs = []
+        try:
+            d_proc = DeviceBuffer((T, Z, Y, X, nc), np.float32).upload(batch_proc)
+            bufs.append(d_proc)
+            d_raw = DeviceBuffer((T, Z, Y, X, nc), br.dtype).upload(br)
+            bufs.append(d_raw)
+            d_flows = DeviceBuffer((T, Z, Y, X, 3), np.float32)
+            bufs.append(d_flows)
+            d_reg = DeviceBuffer((T, Z, Y, X, nc), br.dtype)
+            bufs.append(d_reg)
+            cb_error = []
+
+            def _progress(n, _user):
+                if progress_callback is not None:
+                    try:
+                        progress_callback(int(n))
+                    except Exception as e:
+                        cb_error.append(e)
+
+            cb = _lib.PROGRESS_FN(_progress)
+            _lib.check(lib.fr3d_process_batch_raw_dev(C.byref(params), d_proc.ptr, d_raw.ptr, code, ref_ptrs["reference_proc"],
+                                                      ref_ptrs["reference_raw"], _lib.F32, ref_ptrs.get("w_init"),
+                                                      ref_ptrs.get("weight"), T, Z, Y, X, nc, order, d_flows.ptr, d_reg.ptr,
+                                                      cb, None))
+            if cb_error:
+                raise cb_error[0]
+            flows = d_flows.download()
+            reg = d_reg.download()
+        finally:
+            for b in bufs:
+                b.free()
+        registered = np.empty_like(batch)
+        registered[...] = reg
+        return registered, flows
+

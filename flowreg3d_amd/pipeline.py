@@ -183,7 +183,14 @@ class BatchMotionCorrectorHip:
                                            interpolation_method=str(_opt(self.options, "interpolation_method", "cubic")),
                                            progress_callback=cb, flow_params=self._flow_params())
 
-    def run(self, video: np.ndarray, reference: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    def run(self, video: np.ndarray, reference: np.ndarray, sink: str = "host"):
+        """-> (registered, flows) as NumPy arrays (``sink="host"``), or a ``DeviceSink`` holding both in HBM
+        (``sink="device"``: batches are uploaded once, preprocessing, flow, warp, w_init updates, statistics and
+        the optional reference update all run on device-resident data)."""
+        if sink == "device":
+            return self._run_device(np.asarray(video), reference)
+        if sink != "host":
+            raise ValueError("sink must be 'host' or 'device'")
         video = np.asarray(video)
         T = video.shape[0]
         self._total, self._done = T, 0
@@ -220,6 +227,103 @@ class BatchMotionCorrectorHip:
         finally:
             self.executor.cleanup()
         return registered, flows
+
+    def _run_device(self, video: np.ndarray, reference: np.ndarray):
+        """The same driver with every per-voxel array resident in HBM (same arithmetic, same call order)."""
+        from .device import DeviceBuffer, DeviceSink
+        from .executor import _RAW_CODES
+        from .preprocess import _DTYPES, _norm_constants, _sigma_table
+        from .core import _order_of, expand_weight
+        if video.dtype not in _RAW_CODES:
+            raise TypeError(f"device sink supports {sorted(str(d) for d in _RAW_CODES)} series, got {video.dtype}")
+        T = video.shape[0]
+        self._total, self._done = T, 0
+        self._setup_reference(reference)
+        Z, Y, X, nc = self.reference_raw.shape
+        nv = Z * Y * X
+        lib = _lib.init(getattr(self.executor, "device", None))
+        dp = C.POINTER(C.c_double)
+        fp = self._flow_params()
+        params = _lib.make_params(fp["alpha"], fp["update_lag"], fp["iterations"], fp["min_level"], fp["levels"], fp["eta"],
+                                  fp["a_smooth"], fp["a_data"], nc, fp["solver_fp64"])
+        order = _order_of(str(_opt(self.options, "interpolation_method", "cubic")))
+        bs = max(1, int(_opt(self.options, "buffer_size", 10)))
+        upd_ref = bool(_opt(self.options, "update_reference", False))
+        use_init = bool(_opt(self.options, "update_initialization_w", True))
+        mins, dens = _norm_constants(video[:1], self.reference_raw, str(_opt(self.options, "channel_normalization", "together")), 1e-8)
+        mins = np.ascontiguousarray(mins, np.float64)
+        dens = np.ascontiguousarray(dens, np.float64)
+        tab = _sigma_table(np.asarray(_opt(self.options, "sigma", None)), nc)
+        sink = DeviceSink(T, Z, Y, X, nc, video.dtype)
+        bufs = []
+
+        def dev(shape, dtype, init=None):
+            b = DeviceBuffer(shape, dtype)
+            bufs.append(b)
+            return b.upload(init) if init is not None else b
+
+        try:
+            raw = dev((bs, Z, Y, X, nc), video.dtype)
+            proc = dev((bs, Z, Y, X, nc), np.float32)
+            proc64 = dev((bs, Z, Y, X, nc), np.float64) if upd_ref else None
+            ref_raw = dev((Z, Y, X, nc), np.float64, self.reference_raw)
+            ref_proc = dev((Z, Y, X, nc), np.float32, self.reference_proc)
+            ref_proc64 = dev((Z, Y, X, nc), np.float64, self.reference_proc) if upd_ref else None
+            new_ref64 = dev((Z, Y, X, nc), np.float64) if upd_ref else None
+            weight = dev((Z, Y, X, nc), np.float32, expand_weight(self.weight, Z, Y, X, nc))
+            w_init = dev((Z, Y, X, 3), np.float32, np.zeros((Z, Y, X, 3), np.float32))
+            zero = dev((Z, Y, X, 3), np.float32, np.zeros((Z, Y, X, 3), np.float32))
+            stats = np.zeros((bs, 6), np.float64)
+
+            def process(n, init_ptr, flows_ptr, reg_ptr, notify):
+                done = []
+                cb = _lib.PROGRESS_FN((lambda k, _u: done.append(int(k))) if notify else (lambda k, _u: None))
+                _lib.check(lib.fr3d_process_batch_raw_dev(C.byref(params), proc.ptr, raw.ptr, _RAW_CODES[video.dtype], ref_proc.ptr,
+                                                          ref_raw.ptr, _lib.F64, init_ptr, weight.ptr, n, Z, Y, X, nc, order,
+                                                          flows_ptr, reg_ptr, cb, None))
+                if notify and self._callbacks:
+                    for k in done:
+                        self._done += k
+                        for f in self._callbacks:
+                            f(self._done, self._total)
+
+            for bi, t0 in enumerate(range(0, T, bs)):
+                n = min(bs, T - t0)
+                raw.upload(video[t0:t0 + n])
+                _lib.check(lib.fr3d_preprocess_dev(raw.ptr, _DTYPES[video.dtype], n, Z, Y, X, nc, mins.ctypes.data_as(dp),
+                                                   dens.ctypes.data_as(dp), tab.ctypes.data_as(dp), 4.0, proc.ptr, _lib.F32))
+                if upd_ref:
+                    _lib.check(lib.fr3d_preprocess_dev(raw.ptr, _DTYPES[video.dtype], n, Z, Y, X, nc, mins.ctypes.data_as(dp),
+                                                       dens.ctypes.data_as(dp), tab.ctypes.data_as(dp), 4.0, proc64.ptr, _lib.F64))
+                fl_ptr, reg_ptr = sink.flows_dev.at(t0), sink.registered_dev.at(t0)
+                if bi == 0:  # w_init = mean flow of the first min(22, T) volumes solved from zero (:342-393)
+                    n_init = min(22, n)
+                    process(n_init, zero.ptr, fl_ptr, reg_ptr, False)
+                    _lib.check(lib.fr3d_mean_stack_dev(fl_ptr, n_init, nv * 3, w_init.ptr))
+                process(n, w_init.ptr if use_init else zero.ptr, fl_ptr, reg_ptr, True)
+                if use_init:  # mean of the last <= 20 flows of the batch (:481-485)
+                    k = min(n, 20)
+                    _lib.check(lib.fr3d_mean_stack_dev(sink.flows_dev.at(t0 + n - k), k, nv * 3, w_init.ptr))
+                _lib.check(lib.fr3d_flow_stats_dev(fl_ptr, n, Z, Y, X, stats.ctypes.data_as(dp)))
+                self.stats.mean_disp.extend(stats[:n, 0].tolist())
+                self.stats.max_disp.extend(stats[:n, 1].tolist())
+                self.stats.mean_div.extend(stats[:n, 2].tolist())
+                self.stats.mean_translation.extend(np.sqrt(stats[:n, 3] ** 2 + stats[:n, 4] ** 2 + stats[:n, 5] ** 2).tolist())
+                if upd_ref:  # compensate_recording_3D.py:525-526, 395-429
+                    _lib.check(lib.fr3d_update_reference_dev(proc64.ptr, _lib.F64, fl_ptr, ref_proc64.ptr, _lib.F64, n, Z, Y, X,
+                                                             nc, order, C.cast(C.c_void_p(new_ref64.ptr), dp)))
+                    self.reference_proc = new_ref64.download()
+                    ref_proc64.upload(self.reference_proc)
+                    ref_proc.upload(self.reference_proc)
+                sink.filled = t0 + n
+            self.w_init = w_init.download()
+        except Exception:
+            sink.free()
+            raise
+        finally:
+            for b in bufs:
+                b.free()
+        return sink
 
 
 def compensate_arr_3D(c1: np.ndarray, c_ref: np.ndarray, options: Any = None,

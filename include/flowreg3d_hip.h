@@ -164,6 +164,11 @@ int fr3d_update_reference_dev(const void *batch_proc, int proc_dtype, const floa
 int fr3d_flow_stats(const float *flows, int T, int Z, int Y, int X, double *out);
 int fr3d_flow_stats_dev(const float *flows, int T, int Z, int Y, int X, double *out);
 
+/* np.mean(stack, axis=0) of `count` float32 arrays of n elements, device pointers: float32 accumulation in
+ * stack order, divided by float32(count) -- the batch driver's w_init updates
+ * (compensate_recording_3D.py:342-393, 481-485) without taking the flows off the device. */
+int fr3d_mean_stack_dev(const float *stack, int count, size_t n, float *out);
+
 /* ---- kernel-level entry points (stage parity tests; host pointers) ---------------------- */
 
 /* imresize_fused_gauss_cubic3D (util/resize_util_3D.py:114-156), one fp32 channel. */

@@ -17,6 +17,50 @@ def test_random_shapes_and_parameters_match_the_oracle(hip, oracle):
     assert bad == 0 and worst < 1e-4, (bad, worst)
 
 
+def test_random_shapes_and_parameters_in_the_default_solver_mode(hip, oracle):
+    """The same generator (1..6 channels, axes of length 1..70) with the solver mode left to the library
+    (FR3D_SOLVER_AUTO: fp32 solver storage + fp64 update arithmetic for one channel -- the benched mode --
+    and fp64 storage for several); bound 2e-4 * max(1, |flow|max) on the mean end-point error."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_vs_oracle
+    bad, worst = fuzz_vs_oracle.run(n_cases=40, seed=23, verbose=False, mode=None)
+    assert bad == 0 and worst < 2e-4, (bad, worst)
+
+
+@pytest.mark.parametrize("C", [4, 5, 8])
+def test_many_channels_match_the_oracle(hip, oracle, C):
+    """C = 4 (last unrolled instantiation), 5 and 8 = FR3D_MAX_CHANNELS (channel loop bound at run time):
+    level_solver_3d.py:356-377 loops over any channel count."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(40 + C)
+    shape = (10, 18, 14)
+    def vol():
+        a = gaussian_filter(rng.random(shape), 1.0, mode="reflect")
+        return ((a - a.min()) / (a.max() - a.min())).astype(np.float32)
+    fixed = np.stack([vol() for _ in range(C)], -1)
+    moving = np.stack([0.97 * gaussian_filter(fixed[..., c], 0.6) + 0.02 for c in range(C)], -1).astype(np.float32)
+    w = rng.uniform(0.2, 1.0, C)
+    for a_smooth in (1.0, 0.5):
+        kw = dict(alpha=(0.3, 0.25, 0.2), update_lag=3, iterations=8, min_level=0, levels=3, eta=0.8, a_smooth=a_smooth,
+                  a_data=0.45, weight=w)
+        want = oracle.get_displacement(fixed, moving, **kw)
+        got = hip.get_displacement(fixed, moving, **kw)
+        epe = np.linalg.norm(got - want, axis=-1)
+        assert epe.mean() < 1e-4, (C, a_smooth, epe.mean(), epe.max())
+
+
+def test_eta_one_runs_like_the_reference(hip, oracle):
+    """eta == 1.0 is legal in the reference (OFOptions allows eta <= 1): every pyramid level has the full size."""
+    rng = np.random.default_rng(2)
+    from scipy.ndimage import gaussian_filter
+    fixed = gaussian_filter(rng.random((8, 12, 12)), 1.0).astype(np.float32)
+    moving = np.roll(fixed, 1, axis=2)
+    kw = dict(alpha=(0.5, 0.5, 0.5), update_lag=3, iterations=5, min_level=0, levels=3, eta=1.0, a_smooth=1.0, a_data=0.45)
+    want = oracle.get_displacement(fixed, moving, **kw)
+    got = hip.get_displacement(fixed, moving, solver_fp64=2, **kw)
+    assert np.linalg.norm(got - want, axis=-1).mean() < 1e-4
+
+
 def test_level_rounded_to_zero_is_rejected_like_the_reference(hip, oracle):
     """An axis of length 1 with eta = 0.5 rounds to 0 on the first coarse level; the reference raises
     ZeroDivisionError in its resampler (util/resize_util_3D.py:116-128)."""

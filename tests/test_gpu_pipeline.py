@@ -107,3 +107,43 @@ def test_flow_statistics_vs_numpy(hip):
     for t in range(2):
         div = np.gradient(w[t, ..., 0], axis=2) + np.gradient(w[t, ..., 1], axis=1) + np.gradient(w[t, ..., 2], axis=0)
         assert abs(dv[t] - float(div.mean())) < 1e-6
+
+
+@pytest.mark.parametrize("dtype,update_ref", [(np.float32, False), (np.uint16, True)])
+def test_device_sink_gives_the_host_path_results(hip, dtype, update_ref):
+    """f-4: run(..., sink="device") keeps registered / w of the series in HBM (DeviceSink) and runs
+    preprocessing, flow, warp, the w_init means, the statistics and update_reference on device-resident data:
+    bit-identical to the host-array driver (same kernels, same order; np.mean(axis=0) of the float32 flows
+    restated as float32 accumulation in stack order)."""
+    from scipy.ndimage import gaussian_filter
+    from flowreg3d_amd.pipeline import BatchMotionCorrectorHip, Options
+    rng = np.random.default_rng(12)
+    shape = (8, 18, 16)
+    ref = gaussian_filter(rng.random(shape), 1.5)[..., None]
+    ref = (ref - ref.min()) / (ref.max() - ref.min())
+    video = np.stack([np.roll(ref, (t % 3) - 1, axis=2) * 0.9 + 0.02 * t for t in range(7)], 0)
+    if dtype == np.uint16:
+        video, ref = (video * 3000 + 100).astype(dtype), ref * 3000 + 100
+    else:
+        video = video.astype(dtype)
+    kw = dict(levels=2, min_level=0, iterations=6, buffer_size=3, weight=[1.0], sigma=[[1.0, 1.0, 1.0, 0.1]],
+              update_reference=update_ref)
+    calls = []
+    host = BatchMotionCorrectorHip(Options(**kw))
+    reg_h, w_h = host.run(video, ref)
+    dev = BatchMotionCorrectorHip(Options(**kw))
+    dev.register_progress_callback(lambda d, t: calls.append((d, t)))
+    sink = dev.run(video, ref, sink="device")
+    try:
+        assert sink.filled == 7 and sink.nbytes == reg_h.nbytes + w_h.nbytes
+        assert np.array_equal(sink.flows(), w_h)
+        assert np.array_equal(sink.registered(), reg_h) and sink.registered().dtype == dtype
+        assert np.array_equal(sink.flows(2, 5), w_h[2:5])
+    finally:
+        sink.free()
+    assert np.array_equal(dev.w_init, host.w_init)
+    assert calls and calls[-1] == (7, 7)
+    for a, b in ((dev.stats.mean_disp, host.stats.mean_disp), (dev.stats.mean_div, host.stats.mean_div)):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-15)
+    if update_ref:
+        assert np.array_equal(dev.reference_proc, host.reference_proc)

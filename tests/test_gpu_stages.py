@@ -159,3 +159,26 @@ def test_median_bit_exact_vs_oracle(hip, oracle, shape):
     x = rng.standard_normal(shape).astype(np.float32)
     x[1, 2, 3] = x[2, 2, 2]  # ties
     assert np.array_equal(hip.median_filter5(x), oracle.median5(x).astype(np.float32))
+
+
+def test_lds_staged_warp_equals_global_gather_bitwise(hip):
+    """k_warp_cubic_lds (coefficient box of a 32x8x4 output tile staged in LDS) against the one-thread-per-
+    voxel global gather (FR3D_WARP=global): same taps, same order -> identical bits, for smooth flows, for
+    flows that push samples out of bounds and for violent flows whose tiles fall back to the global path."""
+    import os
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(17)
+    for shape, amp, smooth in [((20, 37, 70), 2.5, 3.0), ((9, 8, 33), 6.0, 1.0), ((33, 40, 64), 40.0, 0.0),
+                               ((1, 5, 3), 1.0, 0.0), ((64, 64, 64), 1.0, 4.0)]:
+        vol = rng.random(shape).astype(np.float32)
+        ref = rng.random(shape).astype(np.float32)
+        uvw = [amp * (gaussian_filter(rng.standard_normal(shape), smooth) if smooth else rng.standard_normal(shape))
+               for _ in range(3)]
+        uvw = [a.astype(np.float32) for a in uvw]
+        os.environ["FR3D_WARP"] = "global"
+        try:
+            want = hip.imregister_wrapper(vol, *uvw, ref)
+        finally:
+            os.environ.pop("FR3D_WARP", None)
+        got = hip.imregister_wrapper(vol, *uvw, ref)
+        assert np.array_equal(np.asarray(want), np.asarray(got)), shape

@@ -74,3 +74,12 @@ def test_hip_executor_registers_into_the_real_runtime_context():
         assert RuntimeContext.get_parallelization_executor("sequential3d").__name__ == "SequentialExecutor3D"
     finally:
         sys.path.remove(REF_SRC)
+
+
+@pytest.mark.parametrize("method", ["cubic", "linear"])
+def test_oracle_update_reference_matches_reference(oracle, method):
+    """f-4: BatchMotionCorrector._update_reference (compensate_recording_3D.py:395-429), golden written by
+    tools/gen_golden.py with the reference's imregister_wrapper -- bit-identical."""
+    g = golden("f4_update_ref")
+    got = oracle.update_reference(g["batch_proc"], g["w"], g["ref_proc"], method)
+    assert np.array_equal(got, g[f"new_ref_{method}"])

@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
 """A/B timing of the SOR sweep kernels (FR3D_SOR_KERNEL = step | pair6 | pair14) on one box, interleaved.
+Record of the round-2 experiment "two hyperplanes of one iteration per launch" (k_sor_pair.hip in commit
+"WIP: typed raw-volume executor entry ..."): bit-identical to k_sor_step on 26 shape/mode cases, but 14-35 %
+SLOWER (profiles/r02/kprobe*.jsonl: 256^3 90-97 ms against 71-79 ms per volume, 512^3 669-698 against 530-589) --
+the halo row/lane recomputation eats the saved plane reads and the phase barrier halves the duty cycle of the
+loads.  The kernel and the FR3D_SOR_KERNEL switch were removed again; this script needs that commit to run.
 usage (GPU box): python tools/experiments/sor_kernel_probe.py EDGE BATCH [reps] [kernels,comma,separated]"""
 import ctypes as C
 import json

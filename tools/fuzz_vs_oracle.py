@@ -1,5 +1,9 @@
-"""Randomised shapes / parameters: GPU get_displacement (fp64 solver storage) against the CPU oracle.
-usage (GPU box): python tools/fuzz_vs_oracle.py [n_cases] [seed]"""
+"""Randomised shapes / parameters / channel counts (1..6): GPU get_displacement against the CPU oracle, in the
+parity solver mode (solver_fp64=2, fp64 solver storage; bound: mean EPE < 1e-4 * max(1,|flow|max)) or in the
+library's DEFAULT mode (solver_fp64=None -> FR3D_SOLVER_AUTO: fp32 solver storage with fp64 update arithmetic
+for one channel, fp64 storage for several; bound 2e-4 * scale on these small, partly ill-conditioned random
+cases -- the north-star 1e-4 is asserted on the BASELINE configurations, tests/test_gpu_fullsize_parity.py).
+usage (GPU box): python tools/fuzz_vs_oracle.py [n_cases] [seed] [auto|2]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,8 +14,10 @@ from scipy.ndimage import gaussian_filter
 
 
 
-def run(n_cases=40, seed=0, verbose=True):
-    """-> (number of failing cases, worst mean EPE relative to max(1, |flow|max))"""
+def run(n_cases=40, seed=0, verbose=True, mode=2):
+    """-> (number of failing cases, worst mean EPE relative to max(1, |flow|max)); mode 2 = fp64 solver storage,
+    None = the library's automatic choice"""
+    tol = 1e-4 if mode == 2 else 2e-4
     say = print if verbose else (lambda *a, **k: None)
     rng = np.random.default_rng(seed)
     _lib.init()
@@ -21,7 +27,7 @@ def run(n_cases=40, seed=0, verbose=True):
         shape = tuple(int(v) for v in rng.choice([1, 2, 3, 5, 6, 7, 9, 16, 23, 31, 40, 65, 70], size=3))
         if np.prod(shape) > 120000:
             shape = (shape[0] % 24 + 1, shape[1], shape[2])
-        C = int(rng.choice([1, 1, 2, 3]))
+        C = int(rng.choice([1, 1, 2, 3, 4, 5, 6]))
         def vol():
             a = gaussian_filter(rng.random(shape), 1.0, mode="reflect")
             return ((a - a.min()) / (a.max() - a.min() + 1e-12)).astype(np.float32)
@@ -42,16 +48,16 @@ def run(n_cases=40, seed=0, verbose=True):
             except ValueError:
                 # input the reference itself rejects (e.g. a pyramid level rounded to size 0): the GPU path must refuse too
                 try:
-                    fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=2, **kw)
+                    fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, **kw)
                     bad += 1
                     say("BAD case %2d shape %s: oracle rejects, GPU path accepted" % (case, shape), flush=True)
                 except (ValueError, RuntimeError):
                     say("ok  case %2d shape %s C=%d: rejected by both" % (case, shape, C), flush=True)
                 continue
-            got = fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=2, **kw)
+            got = fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, **kw)
             d = np.linalg.norm(got - want, axis=-1)
             scale = max(1.0, float(np.abs(want).max()))
-            ok = np.isfinite(got).all() and d.mean() < 1e-4 * scale
+            ok = np.isfinite(got).all() and d.mean() < tol * scale
             worst = max(worst, d.mean() / scale)
             if not ok:
                 bad += 1
@@ -67,5 +73,6 @@ def run(n_cases=40, seed=0, verbose=True):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad, worst = run(n, sd)
+    md = None if (len(sys.argv) > 3 and sys.argv[3] == "auto") else 2
+    bad, worst = run(n, sd, mode=md)
     print("cases %d bad %d worst scaled mean EPE %.2e" % (n, bad, worst))
