@@ -216,6 +216,12 @@ def tensor_factors(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34):
         M[..., r, c] = Js[k]
         M[..., c, r] = Js[k]
     lam, V = np.linalg.eigh(M)          # ascending
+    # the device solver keeps three factors: a tensor that is not (numerically) rank <= 3 -- e.g. one built by
+    # another constancy assumption -- would silently be solved as a different system, so it is refused
+    trace = np.maximum(lam.sum(axis=-1), 0.0)
+    if np.any(np.abs(lam[..., 0]) > 1e-9 * trace + 1e-300):
+        raise ValueError("level_solver: the motion tensor is not rank 3 (smallest eigenvalue exceeds 1e-9 of the trace); "
+                         "the device solver takes the gradient-constancy tensor of get_motion_tensor_gc")
     lam = np.clip(lam[..., 1:], 0.0, None)  # three leading eigenvalues
     V = V[..., :, 1:]
     A = np.sqrt(lam)[..., None, :] * V  # (..., 4, 3): column k = a_k

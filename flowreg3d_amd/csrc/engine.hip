@@ -248,6 +248,10 @@ struct Engine {
         return e;
     }
 
+    // device copies of SciPy's 1-D Gaussian kernels (f-1 preprocessing), uploaded once per (sigma, truncate)
+    std::map<std::pair<long long, long long>, std::pair<double *, int>> gkernels;
+    const double *gauss_kernel(double sigma, double truncate, int &radius);
+
     const DevTable &table(int in_len, int out_len, double sigma)
     {
         long long bits;
@@ -872,6 +876,25 @@ static std::vector<double> gaussian_kernel(double sigma, double truncate, int &r
     return w;
 }
 
+const double *Engine::gauss_kernel(double sigma, double truncate, int &radius)
+{
+    long long a, b;
+    std::memcpy(&a, &sigma, 8);
+    std::memcpy(&b, &truncate, 8);
+    auto key = std::make_pair(a, b);
+    auto it = gkernels.find(key);
+    if (it == gkernels.end()) {
+        int r = 0;
+        std::vector<double> w = sigma > 0.0 ? gaussian_kernel(sigma, truncate, r) : std::vector<double>(1, 1.0);
+        double *d = nullptr;
+        FR3D_HIP(hipMalloc((void **)&d, w.size() * sizeof(double)));
+        FR3D_HIP(hipMemcpy(d, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));  // synchronous, once
+        it = gkernels.emplace(key, std::make_pair(d, r)).first;
+    }
+    radius = it->second.second;
+    return it->second.first;
+}
+
 template <typename TIN>
 static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int X, int C, const double *nmin,
                          const double *nden, const double *sigma, double truncate, void *out, int out_dtype)
@@ -889,11 +912,8 @@ static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int 
         for (int axis = 0; axis < 4; axis++) {
             if (!(ax_sigma[axis] > 1e-15)) continue; // scipy skips these axes
             int radius;
-            std::vector<double> w = gaussian_kernel(ax_sigma[axis], truncate, radius);
+            const double *dw = e.gauss_kernel(ax_sigma[axis], truncate, radius);
             if (radius == 0 && cur) continue;        // kernel [1.0]: x*1.0 is x, nothing to do
-            double *dw = (double *)e.bufs["pp_w" + std::to_string(axis)].ensure(w.size() * sizeof(double));
-            FR3D_HIP(hipMemcpyAsync(dw, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice, e.st));
-            FR3D_HIP(hipStreamSynchronize(e.st));    // w is a host temporary
             if (!cur) launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, axis, dw, radius, dst);
             else launch_gauss_pass<double>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, axis, dw, radius, dst);
             cur = dst;
@@ -901,10 +921,8 @@ static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int 
             passes++;
         }
         if (!cur) {  // no filtering at all: normalisation only (a radius-0 pass)
-            const double one = 1.0;
-            double *dw = (double *)e.bufs["pp_w0"].ensure(sizeof(double));
-            FR3D_HIP(hipMemcpyAsync(dw, &one, sizeof(double), hipMemcpyHostToDevice, e.st));
-            FR3D_HIP(hipStreamSynchronize(e.st));
+            int r0;
+            const double *dw = e.gauss_kernel(0.0, truncate, r0);  // radius 0: the single tap 1.0
             launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, 3, dw, 0, dst);
             cur = dst;
             passes++;
@@ -936,29 +954,21 @@ static void preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, i
     FR3D_HIP(hipStreamSynchronize(e.st));
 }
 
-// host staging helper
+// host staging helper: device copies of caller (host) arrays for the duration of one entry point.  The
+// buffers come from the engine's pool ("stg0", "stg1", ... grown on demand, kept for the next call), so a
+// caller that registers volume after volume through fr3d_get_displacement / fr3d_warp does not pay a
+// hipMalloc + hipFree pair per array and call.
 struct Staged {
-    std::vector<void *> ptrs;
+    int next = 0;
+    void *slot(size_t bytes) { return g_eng.bufs["stg" + std::to_string(next++)].ensure(bytes ? bytes : 1); }
     void *up(const void *host, size_t bytes)
     {
         if (!host) return nullptr;
-        void *d = nullptr;
-        FR3D_HIP(hipMalloc(&d, bytes ? bytes : 1));
-        ptrs.push_back(d);
+        void *d = slot(bytes);
         FR3D_HIP(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
         return d;
     }
-    void *alloc(size_t bytes)
-    {
-        void *d = nullptr;
-        FR3D_HIP(hipMalloc(&d, bytes ? bytes : 1));
-        ptrs.push_back(d);
-        return d;
-    }
-    ~Staged()
-    {
-        for (void *q : ptrs) (void)hipFree(q);
-    }
+    void *alloc(size_t bytes) { return slot(bytes); }
 };
 
 }  // namespace fr3d
@@ -1040,6 +1050,8 @@ void fr3d_shutdown(void)
     g_eng.tables.clear();
     for (auto &kv : g_eng.scheds) free_sor_schedule(kv.second);
     g_eng.scheds.clear();
+    for (auto &kv : g_eng.gkernels) (void)hipFree(kv.second.first);
+    g_eng.gkernels.clear();
     for (auto &s : g_eng.spans) {
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);

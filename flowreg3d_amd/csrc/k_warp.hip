@@ -8,9 +8,6 @@
 //   3. 4x4x4 gather with fp32 coordinates         (ni_interpolation.c NI_GeometricTransform)
 // Each warp is done once per pyramid level, so it is kept reference-exact (fp64 coefficients)
 // rather than minimal in bytes; the bandwidth-critical kernel of the path is the SOR sweep.
-#include <cstdlib>
-#include <cstring>
-
 #include "fr3d_internal.h"
 
 namespace fr3d {
@@ -363,180 +360,63 @@ k_warp_cubic(const double *__restrict__ coef, int npad, const TF *__restrict__ p
     // The taps are summed in SciPy's order (z, y, x innermost; coefficient * wz * wy * wx), but the 16
     // coefficients of a z-tap are fetched together first: written as load-multiply-add per tap the
     // compiler emitted 64 dependent load/wait pairs per voxel.
-    int xi[4], yi[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        xi[e] = clampi(sx + e, PX);
-        yi[e] = clampi(sy + e, PY);
-    }
     double acc = 0.0;
+    // (the range test also catches NaN displacements, whose start index is meaningless)
+    if (sx >= 0 && sy >= 0 && sz >= 0 && sx + 3 < PX && sy + 3 < PY && sz + 3 < PZ) {
+        // coordinates are clipped to [0, N-1] (above), so with a pad of >= 2 the 4^3 taps never leave the
+        // padded grid: no per-tap clamping, the four x-taps of a row are consecutive doubles behind ONE
+        // address (the clamped form spends more VALU work on 64 tap addresses than on the 256 fp64
+        // operations of the interpolation itself)
+        const double *p0 = coef + ((size_t)sz * PY + sy) * PX + sx;
+        const size_t sy_ = (size_t)PX, sz_ = (size_t)PY * PX;
 #pragma unroll
-    for (int a0 = 0; a0 < 4; a0 += WARP_ZB) {
-        double c[WARP_ZB][16];
+        for (int a = 0; a < 4; a++) {
+            double c[16];
 #pragma unroll
-        for (int a = 0; a < WARP_ZB; a++) {
-            const double *slab = coef + (size_t)clampi(sz + a0 + a, PZ) * PY * PX;
+            for (int b = 0; b < 4; b++) {
+                const double *row = p0 + a * sz_ + b * sy_;
 #pragma unroll
-            for (int b = 0; b < 4; b++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) c[a][4 * b + e] = slab[(size_t)yi[b] * PX + xi[e]];
-        }
-#pragma unroll
-        for (int a = 0; a < WARP_ZB; a++)
+                for (int e = 0; e < 4; e++) c[4 * b + e] = row[e];
+            }
 #pragma unroll
             for (int b = 0; b < 4; b++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    double cf = c[a][4 * b + e];
-                    cf *= wz[a0 + a];
+                    double cf = c[4 * b + e];
+                    cf *= wz[a];
                     cf *= wy[b];
                     cf *= wx[e];
                     acc += cf;
                 }
+        }
+    } else {
+        int xi[4], yi[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            xi[e] = clampi(sx + e, PX);
+            yi[e] = clampi(sy + e, PY);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const double *slab = coef + (size_t)clampi(sz + a, PZ) * PY * PX;
+            double c[16];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) c[4 * b + e] = slab[(size_t)yi[b] * PX + xi[e]];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    double cf = c[4 * b + e];
+                    cf *= wz[a];
+                    cf *= wy[b];
+                    cf *= wx[e];
+                    acc += cf;
+                }
+        }
     }
     out[(size_t)t * ocs + oco] = OutCast<TO>::interp(acc);
-}
-
-// The same gather with the coefficients of a workgroup's output tile staged in LDS.  A tile of
-// WT_X x WT_Y x WT_Z outputs whose displacements are smooth touches a slightly larger box of the padded
-// coefficient grid (tile + 3 + the variation of the displacement over the tile): the workgroup finds the
-// box of its in-bounds voxels (LDS atomics), loads it once with coalesced row reads and serves all 64
-// taps of every voxel from LDS -- 2.5-3.5 coefficient reads from HBM/L2 per output instead of 64 through
-// the vector cache.  A tile whose box does not fit (violent or discontinuous displacement) falls back to
-// the global gather, so any flow field gives the same result.  Taps are weighted and summed in SciPy's
-// order exactly like k_warp_cubic: bit-identical output.
-#define WT_X 32
-#define WT_Y 8
-#define WT_Z 4
-#define WT_CAP 6144  // doubles of LDS per workgroup (48 KiB: three workgroups per CU)
-template <typename TF, typename TR, typename TO>
-__global__ void __launch_bounds__(256)
-k_warp_cubic_lds(const double *__restrict__ coef, int npad, const TF *__restrict__ pu,
-                 const TF *__restrict__ pv, const TF *__restrict__ pw, int fs, double hx, double hy,
-                 double hz, const TR *__restrict__ ref, int rcs, int rco, int Z, int Y, int X,
-                 TO *__restrict__ out, int ocs, int oco)
-{
-    __shared__ double tile[WT_CAP];
-    __shared__ int box[6];  // min sx, sy, sz, max sx, sy, sz over the tile's in-bounds voxels
-    const int tid = threadIdx.x;
-    const int tx = tid % WT_X, ty = tid / WT_X;
-    const int x = blockIdx.x * WT_X + tx, y = blockIdx.y * WT_Y + ty, z0 = blockIdx.z * WT_Z;
-    const int PY = Y + 2 * npad, PX = X + 2 * npad, PZ = Z + 2 * npad;
-    if (tid < 3) box[tid] = 0x7fffffff;
-    else if (tid < 6) box[tid] = -1;
-    __syncthreads();
-    float cx[WT_Z], cy[WT_Z], cz[WT_Z];
-    int state[WT_Z];  // 0 outside the volume, 1 out-of-bounds sample (reference value), 2 interpolate
-    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
-#pragma unroll
-    for (int q = 0; q < WT_Z; q++) {
-        const int z = z0 + q;
-        state[q] = 0;
-        cx[q] = cy[q] = cz[q] = 0.0f;
-        if (x < X && y < Y && z < Z) {
-            const size_t t = ((size_t)z * Y + y) * X + x;
-            // core/optical_flow_3d.py:32-34 : (grid + displacement).astype(float32)
-            const float mx = (float)((double)x + (double)pu[t * fs] / hx);
-            const float my = (float)((double)y + (double)pv[t * fs] / hy);
-            const float mz = (float)((double)z + (double)pw[t * fs] / hz);
-            const bool oob = (mx < 0.0f) || (mx >= (float)X) || (my < 0.0f) || (my >= (float)Y) || (mz < 0.0f) ||
-                             (mz >= (float)Z);
-            state[q] = oob ? 1 : 2;
-            if (!oob) {
-                cx[q] = mx > (float)(X - 1) ? (float)(X - 1) : mx;
-                cy[q] = my > (float)(Y - 1) ? (float)(Y - 1) : my;
-                cz[q] = mz > (float)(Z - 1) ? (float)(Z - 1) : mz;
-                const int sx = (int)floor((double)cx[q] + npad) - 1, sy = (int)floor((double)cy[q] + npad) - 1,
-                          sz = (int)floor((double)cz[q] + npad) - 1;
-                lo[0] = min(lo[0], sx); lo[1] = min(lo[1], sy); lo[2] = min(lo[2], sz);
-                hi[0] = max(hi[0], sx); hi[1] = max(hi[1], sy); hi[2] = max(hi[2], sz);
-            }
-        }
-    }
-    if (hi[0] >= 0) {
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            atomicMin(&box[d], lo[d]);
-            atomicMax(&box[3 + d], hi[d]);
-        }
-    }
-    __syncthreads();
-    const int bx0 = box[0], by0 = box[1], bz0 = box[2];
-    const int bnx = box[3] - bx0 + 4, bny = box[4] - by0 + 4, bnz = box[5] - bz0 + 4;
-    const bool any = box[3] >= 0;
-    const bool staged = any && (long long)bnx * bny * bnz <= WT_CAP;
-    if (staged) {
-        const int vol = bnx * bny * bnz;
-        for (int e = tid; e < vol; e += 256) {
-            const int xx = e % bnx, r = e / bnx;
-            const int yy = r % bny, zz = r / bny;
-            tile[e] = coef[((size_t)clampi(bz0 + zz, PZ) * PY + clampi(by0 + yy, PY)) * PX + clampi(bx0 + xx, PX)];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < WT_Z; q++) {
-        if (state[q] == 0) continue;
-        const size_t t = ((size_t)(z0 + q) * Y + y) * X + x;
-        if (state[q] == 1) {
-            out[t * ocs + oco] = OutCast<TO>::oob((float)ref[t * rcs + rco]);
-            continue;
-        }
-        double wz[4], wy[4], wx[4];
-        int sz, sy, sx;
-        bspline3_weights((double)cz[q] + npad, wz, &sz);
-        bspline3_weights((double)cy[q] + npad, wy, &sy);
-        bspline3_weights((double)cx[q] + npad, wx, &sx);
-        double acc = 0.0;
-        if (staged) {
-            const double *base = tile + ((size_t)(sz - bz0) * bny + (sy - by0)) * bnx + (sx - bx0);
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                double c[16];
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) c[4 * b + e] = base[((size_t)a * bny + b) * bnx + e];
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        double cf = c[4 * b + e];
-                        cf *= wz[a];
-                        cf *= wy[b];
-                        cf *= wx[e];
-                        acc += cf;
-                    }
-            }
-        } else {
-            int xi[4], yi[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                xi[e] = clampi(sx + e, PX);
-                yi[e] = clampi(sy + e, PY);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                const double *slab = coef + (size_t)clampi(sz + a, PZ) * PY * PX;
-                double c[16];
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) c[4 * b + e] = slab[(size_t)yi[b] * PX + xi[e]];
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        double cf = c[4 * b + e];
-                        cf *= wz[a];
-                        cf *= wy[b];
-                        cf *= wx[e];
-                        acc += cf;
-                    }
-            }
-        }
-        out[t * ocs + oco] = OutCast<TO>::interp(acc);
-    }
 }
 
 template <typename TF, typename TR, typename TO>
@@ -544,16 +424,9 @@ void launch_warp_cubic(hipStream_t st, const double *coef, int npad, const TF *p
                        const TF *pw, int fs, double hx, double hy, double hz, const TR *ref,
                        int rcs, int rco, int Z, int Y, int X, TO *out, int ocs, int oco)
 {
-    const char *env = getenv("FR3D_WARP");  // "global": the one-thread-per-voxel gather without LDS staging
-    const long long gy = cdiv(Y, WT_Y), gz = cdiv(Z, WT_Z);
-    if ((env && !strcmp(env, "global")) || gy > 65535 || gz > 65535) {
-        long long total = (long long)Z * Y * X;
-        hipLaunchKernelGGL((k_warp_cubic<TF, TR, TO>), dim3(cdiv(total, 256)), dim3(256), 0, st, coef,
-                           npad, pu, pv, pw, fs, hx, hy, hz, ref, rcs, rco, Z, Y, X, out, ocs, oco);
-    } else {
-        hipLaunchKernelGGL((k_warp_cubic_lds<TF, TR, TO>), dim3(cdiv(X, WT_X), (unsigned)gy, (unsigned)gz), dim3(256), 0,
-                           st, coef, npad, pu, pv, pw, fs, hx, hy, hz, ref, rcs, rco, Z, Y, X, out, ocs, oco);
-    }
+    long long total = (long long)Z * Y * X;
+    hipLaunchKernelGGL((k_warp_cubic<TF, TR, TO>), dim3(cdiv(total, 256)), dim3(256), 0, st, coef,
+                       npad, pu, pv, pw, fs, hx, hy, hz, ref, rcs, rco, Z, Y, X, out, ocs, oco);
     FR3D_LAUNCH_CHECK();
 }
 #define FR3D_WARP_CUBIC_INST(TF, TR, TO)                                                                       \

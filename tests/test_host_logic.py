@@ -137,3 +137,21 @@ def test_pipeline_option_helpers_follow_ofoptions():
     assert _weight_at([0.6], 0, 2) == 0.6 and _weight_at([0.6, 0.4], 2, 3) == pytest.approx(1 / 3)
     w3 = np.arange(2 * 2 * 2 * 2, dtype=float).reshape(2, 2, 2, 2)
     assert np.array_equal(_weight_at(w3, 1, 2), w3[1])
+
+
+def test_tensor_factors_refuses_a_tensor_that_is_not_rank_three():
+    """The device solver rebuilds the motion tensor from three square-root factors; a rank-4 tensor (another
+    constancy assumption) must be rejected, not silently solved as a different system."""
+    import pytest
+    from conftest import golden
+    from flowreg3d_amd.core import tensor_factors
+    J = golden("k3_tensor")["J"]
+    Ji = [J[i][1:-1, 1:-1, 1:-1] for i in range(10)]
+    A = tensor_factors(*Ji)
+    assert A.shape == (12,) + Ji[0].shape
+    # J = sum_k a_k a_k^T reproduces the entries (index 4k + column; J11 = sum_k a_k[0]^2)
+    np.testing.assert_allclose(A[0] ** 2 + A[4] ** 2 + A[8] ** 2, Ji[0], rtol=1e-9, atol=1e-12)
+    bad = [j.copy() for j in Ji]
+    bad[3] = bad[3] + 1.0  # J44 alone: a fourth independent direction
+    with pytest.raises(ValueError):
+        tensor_factors(*bad)
