@@ -87,6 +87,7 @@ SIGNATURES = {
     "fr3d_flow_stats": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "fr3d_flow_stats_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "fr3d_resize3d": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "fr3d_resize3d_ex": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _vp]),
     "fr3d_motion_tensor": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     "fr3d_level_solve": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,
                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _vp]),

@@ -157,15 +157,11 @@ def imregister_wrapper(f2_level, u, v, w, f1_level, interpolation_method="cubic"
 
 
 def imresize_fused_gauss_cubic3D(img, size, sigma_coeff=0.6, per_axis=False):
-    """util/resize_util_3D.py:114-156 for floating-point input (per_axis=False, sigma_coeff=0.6 --
-    the only form the flow path uses)."""
-    if per_axis or float(sigma_coeff) != 0.6:
-        raise NotImplementedError("only sigma_coeff=0.6, per_axis=False (the flow path's form)")
+    """util/resize_util_3D.py:114-156: fused Gauss x cubic separable resampling on the device.  Integer
+    images are rounded and clipped to their dtype's range on the way back, like the reference (:150-154)."""
     img = np.asarray(img)
     if img.ndim not in (3, 4):
         raise ValueError("img must be 3D or 4D with channels-last")
-    if np.issubdtype(img.dtype, np.integer):
-        raise NotImplementedError("integer images are not on the flow path")
     od, oh, ow = (int(s) for s in size[:3])
     x = img.astype(np.float32, copy=False)
     x4 = x[..., None] if x.ndim == 3 else x
@@ -175,10 +171,16 @@ def imresize_fused_gauss_cubic3D(img, size, sigma_coeff=0.6, per_axis=False):
     for c in range(nc):
         src = np.ascontiguousarray(x4[..., c])
         dst = np.empty((od, oh, ow), np.float32)
-        _lib.check(lib.fr3d_resize3d(_lib.ptr(src), D, H, W, od, oh, ow, _lib.ptr(dst)))
+        _lib.check(lib.fr3d_resize3d_ex(_lib.ptr(src), D, H, W, od, oh, ow, float(sigma_coeff), int(bool(per_axis)),
+                                        _lib.ptr(dst)), value_error=True)
         out[..., c] = dst
     if x.ndim == 3:
         out = out[..., 0]
+    if np.issubdtype(img.dtype, np.integer):
+        info = np.iinfo(img.dtype)
+        out = np.rint(out)
+        np.clip(out, info.min, info.max, out=out)
+        return out.astype(img.dtype)
     return out.astype(img.dtype, copy=False)
 
 

@@ -315,16 +315,22 @@ static void ensure_init()
 // imresize_fused_gauss_cubic3D for one channel: src (D,H,W) with channel stride cs/offset co
 // -> planar dst (od,oh,ow)
 static void resize3d(Engine &e, const float *src, int cs, int co, int D, int H, int W, int od, int oh,
-                     int ow, float *dst)
+                     int ow, float *dst, double sigma_coeff = 0.6, bool per_axis = false)
 {
     double sz = (double)od / D, sy = (double)oh / H, sx = (double)ow / W;
     double s = sx;
     if (sy < s) s = sy;
     if (sz < s) s = sz;
-    double sig = (s < 1.0) ? (0.6 / s) : 0.0;
-    const DevTable &tx = e.table(W, ow, sig);
-    const DevTable &ty = e.table(H, oh, sig);
-    const DevTable &tz = e.table(D, od, sig);
+    double sig = (s < 1.0) ? (sigma_coeff / s) : 0.0;
+    double sigx = sig, sigy = sig, sigz = sig;
+    if (per_axis) {  // util/resize_util_3D.py:120-123: each axis' sigma from its own scale
+        sigx = sx < 1.0 ? sigma_coeff / sx : 0.0;
+        sigy = sy < 1.0 ? sigma_coeff / sy : 0.0;
+        sigz = sz < 1.0 ? sigma_coeff / sz : 0.0;
+    }
+    const DevTable &tx = e.table(W, ow, sigx);
+    const DevTable &ty = e.table(H, oh, sigy);
+    const DevTable &tz = e.table(D, od, sigz);
     float *t1 = e.f32("rs_t1", (size_t)D * H * ow);
     float *t2 = e.f32("rs_t2", (size_t)D * oh * ow);
     double bytes = 4.0 * ((double)D * H * W + 2.0 * D * H * ow + 2.0 * D * oh * ow + (double)od * oh * ow);
@@ -1382,13 +1388,20 @@ int fr3d_flow_stats(const float *flows, int T, int Z, int Y, int X, double *out)
 
 int fr3d_resize3d(const float *src, int D, int H, int W, int od, int oh, int ow, float *dst)
 {
+    return fr3d_resize3d_ex(src, D, H, W, od, oh, ow, 0.6, 0, dst);
+}
+
+int fr3d_resize3d_ex(const float *src, int D, int H, int W, int od, int oh, int ow, double sigma_coeff, int per_axis,
+                     float *dst)
+{
     FR3D_TRY
     ensure_init();
     FR3D_CHECK(src && dst && D > 0 && H > 0 && W > 0 && od > 0 && oh > 0 && ow > 0, "bad resize arguments");
+    FR3D_CHECK(sigma_coeff >= 0.0 && sigma_coeff * std::max(D, std::max(H, W)) < 4096.0, "sigma_coeff out of range");
     Staged s;
     const float *ds = (const float *)s.up(src, (size_t)D * H * W * 4);
     float *dd = (float *)s.alloc((size_t)od * oh * ow * 4);
-    resize3d(g_eng, ds, 1, 0, D, H, W, od, oh, ow, dd);
+    resize3d(g_eng, ds, 1, 0, D, H, W, od, oh, ow, dd, sigma_coeff, per_axis != 0);
     FR3D_HIP(hipStreamSynchronize(g_eng.st));
     FR3D_HIP(hipMemcpy(dst, dd, (size_t)od * oh * ow * 4, hipMemcpyDeviceToHost));
     FR3D_CATCH

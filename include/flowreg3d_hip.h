@@ -173,6 +173,10 @@ int fr3d_mean_stack_dev(const float *stack, int count, size_t n, float *out);
 
 /* imresize_fused_gauss_cubic3D (util/resize_util_3D.py:114-156), one fp32 channel. */
 int fr3d_resize3d(const float *src, int D, int H, int W, int od, int oh, int ow, float *dst);
+/* the same with the function's other arguments: sigma_coeff (0.6 on the flow path) and per_axis (each axis'
+ * Gaussian sigma from its own scale factor, :120-123) */
+int fr3d_resize3d_ex(const float *src, int D, int H, int W, int od, int oh, int ow, double sigma_coeff,
+                     int per_axis, float *dst);
 
 /* get_motion_tensor_gc (core/optical_flow_3d.py:92-152) for one channel.  f1,f2 (Z,Y,X) fp32;
  * J: 10 x (Z,Y,X) fp32 interior values, order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34.

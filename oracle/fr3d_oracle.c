@@ -149,25 +149,37 @@ int fr3d_oracle_resize_tables(int in_len, int out_len, double sigma, int *idx, f
 void fr3d_oracle_resize3d(const float *src, int D, int H, int W, int od, int oh, int ow,
                           double sigma_coeff, float *dst)
 {
-    /* util/resize_util_3D.py:114-138, per_axis=False */
+    fr3d_oracle_resize3d_ex(src, D, H, W, od, oh, ow, sigma_coeff, 0, dst);
+}
+
+void fr3d_oracle_resize3d_ex(const float *src, int D, int H, int W, int od, int oh, int ow,
+                             double sigma_coeff, int per_axis, float *dst)
+{
+    /* util/resize_util_3D.py:114-138 */
     double sz = (double)od / (double)D, sy = (double)oh / (double)H, sx = (double)ow / (double)W;
     double s = sx;
     if (sy < s) s = sy;
     if (sz < s) s = sz;
     double sig = (s < 1.0) ? (sigma_coeff / s) : 0.0;
+    double sigx = sig, sigy = sig, sigz = sig;
+    if (per_axis) { /* :120-123 */
+        sigx = sx < 1.0 ? sigma_coeff / sx : 0.0;
+        sigy = sy < 1.0 ? sigma_coeff / sy : 0.0;
+        sigz = sz < 1.0 ? sigma_coeff / sz : 0.0;
+    }
 
-    int Px = fr3d_oracle_resize_tables(W, ow, sig, NULL, NULL);
-    int Py = fr3d_oracle_resize_tables(H, oh, sig, NULL, NULL);
-    int Pz = fr3d_oracle_resize_tables(D, od, sig, NULL, NULL);
+    int Px = fr3d_oracle_resize_tables(W, ow, sigx, NULL, NULL);
+    int Py = fr3d_oracle_resize_tables(H, oh, sigy, NULL, NULL);
+    int Pz = fr3d_oracle_resize_tables(D, od, sigz, NULL, NULL);
     int *ix = (int *)xmalloc(sizeof(int) * (size_t)ow * Px);
     int *iy = (int *)xmalloc(sizeof(int) * (size_t)oh * Py);
     int *iz = (int *)xmalloc(sizeof(int) * (size_t)od * Pz);
     float *wx = (float *)xmalloc(sizeof(float) * (size_t)ow * Px);
     float *wy = (float *)xmalloc(sizeof(float) * (size_t)oh * Py);
     float *wz = (float *)xmalloc(sizeof(float) * (size_t)od * Pz);
-    fr3d_oracle_resize_tables(W, ow, sig, ix, wx);
-    fr3d_oracle_resize_tables(H, oh, sig, iy, wy);
-    fr3d_oracle_resize_tables(D, od, sig, iz, wz);
+    fr3d_oracle_resize_tables(W, ow, sigx, ix, wx);
+    fr3d_oracle_resize_tables(H, oh, sigy, iy, wy);
+    fr3d_oracle_resize_tables(D, od, sigz, iz, wz);
 
     float *t1 = (float *)xmalloc(sizeof(float) * (size_t)D * H * ow);
     float *t2 = (float *)xmalloc(sizeof(float) * (size_t)D * oh * ow);

@@ -29,6 +29,9 @@ int fr3d_oracle_resize_tables(int in_len, int out_len, double sigma, int *idx, f
 /* util/resize_util_3D.py:114-156 for one channel (D,H,W) fp32 -> (od,oh,ow) fp32. */
 void fr3d_oracle_resize3d(const float *src, int D, int H, int W, int od, int oh, int ow,
                           double sigma_coeff, float *dst);
+/* the same with per_axis (:120-123: one Gaussian sigma per axis from that axis' own scale) */
+void fr3d_oracle_resize3d_ex(const float *src, int D, int H, int W, int od, int oh, int ow,
+                             double sigma_coeff, int per_axis, float *dst);
 
 /* scipy.ndimage.spline_filter(order=3, mode='nearest', output=float64) on a contiguous
  * (Z,Y,X) fp64 array, in place (axis 0, then 1, then 2). */

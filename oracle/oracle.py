@@ -66,8 +66,8 @@ def resize_tables(in_len: int, out_len: int, sigma: float):
     return idx, wt
 
 
-def imresize_fused_gauss_cubic3D(img, size, sigma_coeff=0.6):
-    """util/resize_util_3D.py:114 (per_axis=False, float inputs)."""
+def imresize_fused_gauss_cubic3D(img, size, sigma_coeff=0.6, per_axis=False):
+    """util/resize_util_3D.py:114-156 (float and integer images)."""
     img = np.asarray(img)
     od, oh, ow = (int(s) for s in size[:3])
     x = np.ascontiguousarray(img, dtype=np.float32)
@@ -83,10 +83,15 @@ def imresize_fused_gauss_cubic3D(img, size, sigma_coeff=0.6):
     for c in range(Cn):
         src = np.ascontiguousarray(x[..., c])
         dst = np.empty((od, oh, ow), np.float32)
-        lib().fr3d_oracle_resize3d(_f(src), D, H, W, od, oh, ow, C.c_double(sigma_coeff), _f(dst))
+        lib().fr3d_oracle_resize3d_ex(_f(src), D, H, W, od, oh, ow, C.c_double(sigma_coeff), int(bool(per_axis)), _f(dst))
         out[..., c] = dst
     if squeeze:
         out = out[..., 0]
+    if np.issubdtype(img.dtype, np.integer):  # :150-154 round, clip to the dtype's range, cast
+        info = np.iinfo(img.dtype)
+        out = np.rint(out)
+        np.clip(out, info.min, info.max, out=out)
+        return out.astype(img.dtype)
     return out.astype(img.dtype, copy=False)
 
 

@@ -84,6 +84,46 @@ def test_cfg4_lockstep_batch_equals_single_volumes(hip, pair256):
         assert np.array_equal(reg[t, ..., 0], np.asarray(r, dtype=np.float32).reshape(fixed.shape)), t
 
 
+def test_cfg4_per_gpu_share_as_stated(hip, pair256):
+    """BASELINE config 4 as stated: 64 time points of 256^3 over 8 GPUs = 8 volumes per GPU against the fixed
+    reference, full 100 iterations, motion amplitude x sin(2 pi t / 64).  This is rank 0's shard (t = 0, 8, ...,
+    56; the sharding itself is tests/test_gpu_distributed.py and tests/test_distributed_cpu.py): one
+    process_batch call at lock-step batch 8, checked against single-volume calls (bit-identical), against the
+    known motion, and t = 0 (amplitude 0, moving == fixed) gives exactly zero flow."""
+    import flowreg3d_amd as fr
+    from flowreg3d_amd import _lib
+    from flowreg3d_amd.distributed import shard_indices
+    from flowreg3d_amd.executor import HipExecutor3D
+    from flowreg3d_amd.synthetic import fast_pair
+    fixed = pair256[0]
+    mine = shard_indices(64, 0, 8)
+    assert mine == list(range(0, 64, 8)) and len(mine) == 8
+    base = np.array((1.7, -1.1, 0.6))
+    amps = [float(np.sin(2.0 * np.pi * t / 64.0)) for t in mine]
+    batch = np.stack([fast_pair(fixed.shape, shift=tuple(base * a))[1] for a in amps])[..., None].astype(np.float32)
+    fp = dict(SOLVER, min_level=0, levels=4)
+    assert fp["iterations"] == 100
+    w0 = np.zeros(fixed.shape + (3,), np.float32)
+    lib = _lib.load()
+    lib.fr3d_set_batch(8)
+    try:
+        with HipExecutor3D() as ex:
+            reg, flows = ex.process_batch(batch, batch, fixed[..., None], fixed[..., None], w0, None, None, flow_params=fp)
+    finally:
+        lib.fr3d_set_batch(0)
+    assert flows.shape == (8, 256, 256, 256, 3) and np.isfinite(flows).all() and reg.shape == batch.shape
+    assert not flows[0].any() and np.array_equal(reg[0], batch[0])          # t = 0: no motion
+    for i in (2, 5):                                                         # lock-step batch == single calls
+        single = fr.get_displacement(fixed, batch[i, ..., 0], uvw=w0.copy(), **fp).astype(np.float32)
+        assert np.array_equal(flows[i], single), i
+    for i, a in enumerate(amps):                                             # the known translation is recovered
+        err = np.linalg.norm(_interior(flows[i], 24) - (base * a).astype(np.float32), axis=-1)
+        assert err.mean() < 0.08, (i, a, err.mean())
+        before = np.abs(_interior(batch[i, ..., 0], 24) - _interior(fixed, 24)).mean()
+        after = np.abs(_interior(reg[i, ..., 0], 24) - _interior(fixed, 24)).mean()
+        assert after <= 0.1 * before + 1e-6, (i, before, after)
+
+
 def test_cfg2_256_coarse_levels_vs_oracle(hip, oracle, pair256):
     """Full-size input, solver on the two coarsest levels of the schedule only (84^3, 105^3), 20
     iterations: the oracle finishes in ~15 s and every full-size resample (fixed, moving, flow

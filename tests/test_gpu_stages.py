@@ -180,3 +180,18 @@ def test_warp_survives_nan_and_huge_displacements(hip):
     assert np.allclose(got[mask], vol[mask], atol=1e-6)          # zero displacement: the volume itself
     for p in ((1, 1, 1), (2, 2, 2), (3, 3, 3), (4, 4, 4)):
         assert got[p] == ref[p]                                   # out of bounds -> reference value
+
+
+def test_resampler_options_match_the_reference(hip):
+    """imresize_fused_gauss_cubic3D with per_axis / sigma_coeff / integer images (fr3d_resize3d_ex) against the
+    reference's own outputs (tests/golden/k1_resize_opts.npz): bit-exact, like the flow path's form."""
+    from conftest import golden
+    g = golden("k1_resize_opts")
+    vol = g["vol"]
+    assert np.array_equal(hip.imresize_fused_gauss_cubic3D(vol, (11, 22, 30), per_axis=True), g["per_axis"])
+    assert np.array_equal(hip.imresize_fused_gauss_cubic3D(vol, (9, 15, 13), sigma_coeff=0.9, per_axis=True), g["per_axis_s09"])
+    assert np.array_equal(hip.imresize_fused_gauss_cubic3D(vol, (11, 15, 17), sigma_coeff=0.3), g["s03"])
+    for key, src, size, kw in (("u16_down", "u16", (11, 15, 17), {}), ("u16_up", "u16", (23, 28, 33), {}),
+                               ("i16_mixed", "i16", (18, 30, 13), dict(per_axis=True))):
+        got = hip.imresize_fused_gauss_cubic3D(g[src], size, **kw)
+        assert got.dtype == g[key].dtype and np.array_equal(got, g[key]), key

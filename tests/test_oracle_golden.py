@@ -114,3 +114,17 @@ def test_zero_sized_pyramid_level_is_rejected():
     with pytest.raises(ValueError):
         oracle.get_displacement(fixed, fixed, alpha=(1, 1, 1), update_lag=5, iterations=4, min_level=3, levels=9,
                                 eta=0.5, a_smooth=1.0, a_data=0.45)
+
+
+def test_resampler_options_off_the_flow_path(oracle):
+    """per_axis, sigma_coeff and integer images of imresize_fused_gauss_cubic3D (util/resize_util_3D.py:114-156):
+    bit-identical to the reference's own outputs."""
+    g = golden("k1_resize_opts")
+    vol = g["vol"]
+    assert np.array_equal(oracle.imresize_fused_gauss_cubic3D(vol, (11, 22, 30), per_axis=True), g["per_axis"])
+    assert np.array_equal(oracle.imresize_fused_gauss_cubic3D(vol, (9, 15, 13), sigma_coeff=0.9, per_axis=True), g["per_axis_s09"])
+    assert np.array_equal(oracle.imresize_fused_gauss_cubic3D(vol, (11, 15, 17), sigma_coeff=0.3), g["s03"])
+    for key, src, size, kw in (("u16_down", "u16", (11, 15, 17), {}), ("u16_up", "u16", (23, 28, 33), {}),
+                               ("i16_mixed", "i16", (18, 30, 13), dict(per_axis=True))):
+        got = oracle.imresize_fused_gauss_cubic3D(g[src], size, **kw)
+        assert got.dtype == g[key].dtype and np.array_equal(got, g[key]), key

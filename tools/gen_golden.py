@@ -102,6 +102,22 @@ def main():
         out["down4"] = rz.imresize_fused_gauss_cubic3D(vol4, (12, 14, 20))
         save("k1_resize", **out)
 
+    # ---- K1 options off the flow path: per_axis, sigma_coeff, integer images (util/resize_util_3D.py:114-156)
+    if want("k1_resize_opts"):
+        vol = smooth_volume((18, 22, 26), 7)
+        out = dict(vol=vol)
+        out["per_axis"] = rz.imresize_fused_gauss_cubic3D(vol, (11, 22, 30), per_axis=True)
+        out["per_axis_s09"] = rz.imresize_fused_gauss_cubic3D(vol, (9, 15, 13), sigma_coeff=0.9, per_axis=True)
+        out["s03"] = rz.imresize_fused_gauss_cubic3D(vol, (11, 15, 17), sigma_coeff=0.3)
+        u16 = (vol * 60000.0 + 2000.0).astype(np.uint16)
+        out["u16"] = u16
+        out["u16_down"] = rz.imresize_fused_gauss_cubic3D(u16, (11, 15, 17))
+        out["u16_up"] = rz.imresize_fused_gauss_cubic3D(u16, (23, 28, 33))
+        i16 = (vol * 60000.0 - 30000.0).astype(np.int16)
+        out["i16"] = i16
+        out["i16_mixed"] = rz.imresize_fused_gauss_cubic3D(i16, (18, 30, 13), per_axis=True)
+        save("k1_resize_opts", **out)
+
     # ---- K2: warp (cubic B-spline with prefilter / linear) ---------------------------------
     if want("k2_warp"):
         out = {}
