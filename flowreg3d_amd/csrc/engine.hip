@@ -432,6 +432,9 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         S *wsk = (S *)e.bufs["w_sk" + sn].ensure(ns * C * sizeof(S));
         S *Lbuf = (S *)e.bufs["L_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
         S *dbuf = (S *)e.bufs["d_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
+        // a_smooth == 1: record layout for the sweep kernel (k_sor.hip); otherwise the a_smooth != 1 kernels
+        // (k_sor_smooth.hip) read one array per operand.  Both arrangements fill the same slabs.
+        const bool fast = p.a_smooth == 1.0;
         SorArgsT<S> a;
         std::memset(&a, 0, sizeof(a));
         a.sk = sk;
@@ -447,15 +450,13 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         a.ay = (sc * p.alpha[1]) / (hy * hy);
         a.az = (sc * p.alpha[2]) / (hz * hz);
         for (int c = 0; c < C; c++) {
-            for (int q = 0; q < 12; q++) a.A[q * FR3D_MAX_CHANNELS + c] = Abuf + ((size_t)c * 12 + q) * ns;
+            a.A[c] = Abuf + (size_t)c * 12 * ns;
             a.weight[c] = wsk + (size_t)c * ns;
             a.a_data[c] = p.a_data[c];
         }
-        for (int q = 0; q < 9; q++) a.M[q] = Mbuf + (size_t)q * ns;
-        for (int d = 0; d < 3; d++) {
-            a.L[d] = Lbuf + (size_t)d * ns;
-            a.d[d] = dbuf + (size_t)d * ns;
-        }
+        a.M = Mbuf;
+        a.L = Lbuf;
+        a.d = dbuf;
         {
             Span sp(e, FR3D_K_OTHER, 0, 0, 0);
             launch_skew_copy_n<float, S>(e.st, rp.wl[li], (long long)nl, wsk, (long long)ns, C, sk);
@@ -500,12 +501,14 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                     float *Jo[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
                     launch_motion_tensor<S>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
                                             hx, Jo, nat, (long long)nl, nullptr);
-                    launch_skew_copy_n<S, S>(e.st, nat, (long long)nl, Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns,
-                                             (long long)ns, 12, sk);
+                    S *Adst = Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns;
+                    if (fast) launch_skew_pack<S, S>(e.st, nat, (long long)nl, Adst, 12, sk);
+                    else launch_skew_copy_n<S, S>(e.st, nat, (long long)nl, Adst, (long long)ns, 12, sk);
                 }
                 S *Ln = nat + 12 * nl;
                 launch_laplace<S>(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Ln, Ln + nl, Ln + 2 * nl, true);
-                launch_skew_copy_n<S, S>(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, (long long)ns, 3, sk);
+                if (fast) launch_skew_pack<S, S>(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, 3, sk);
+                else launch_skew_copy_n<S, S>(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, (long long)ns, 3, sk);
             }
         }
         a.iterations = p.iterations;
@@ -533,10 +536,10 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 }
                 FR3D_HIP(hipMemsetAsync(smD, 0, ns * 9 * sizeof(S), e.st));
                 sa.Ps = smP;
-                for (int q = 0; q < 9; q++) sa.M[q] = a.M[q] + (size_t)b * a.vsM;
+                for (int q = 0; q < 9; q++) sa.M[q] = Mbuf + (size_t)b * a.vsM + (size_t)q * ns;
                 for (int c = 0; c < C; c++) {
                     for (int q = 0; q < 12; q++)
-                        sa.A[q * FR3D_MAX_CHANNELS + c] = a.A[q * FR3D_MAX_CHANNELS + c] + (size_t)b * a.vsA;
+                        sa.A[q * FR3D_MAX_CHANNELS + c] = Abuf + (size_t)b * a.vsA + ((size_t)c * 12 + q) * ns;
                     sa.weight[c] = a.weight[c];
                     sa.a_data[c] = p.a_data[c];
                 }
@@ -562,7 +565,8 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 Span sp(e, FR3D_K_OTHER, 0, 0, 0);
                 // increments leave the solver rounded to fp32: the next level (and the executor) cast to
                 // fp32 anyway (util/resize_util_3D.py:116, sequential_3d.py:150) and the median commutes with it
-                launch_unskew_copy_n<S, float>(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
+                if (fast) launch_unskew_unpack<S, float>(e.st, dbuf + (size_t)b * a.vsD, dn, (long long)nl, 3, sk);
+                else launch_unskew_copy_n<S, float>(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
             }
             if (med) {
                 Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);
@@ -1451,18 +1455,21 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     float *Lb = (float *)s.alloc(ns * 3 * 4);
     float *db = (float *)s.alloc(ns * 3 * 4);
     float *dn = (float *)s.alloc(n * 3 * 4);
+    const bool fast = a_smooth == 1.0;  // record layout (k_sor.hip) / one array per operand (k_sor_smooth.hip)
+    float *Lnat = (float *)s.alloc(n * 3 * 4);
     SorArgs a;
     std::memset(&a, 0, sizeof(a));
     a.sk = sk;
     a.C = C;
-    for (int q = 0; q < 9; q++) a.M[q] = Msk + (size_t)q * ns;
-    for (int q = 0; q < 12; q++)
-        for (int c = 0; c < C; c++) {
-            float *dst = Ask + ((size_t)q * C + c) * ns;
-            launch_skew_copy_n<float, float>(e.st, dA + ((size_t)q * C + c) * n, 0, dst, 0, 1, sk);
-            a.A[q * FR3D_MAX_CHANNELS + c] = dst;
-        }
+    a.M = Msk;
+    a.L = Lb;
+    a.d = db;
+    // A arrives as (12, C, Z, Y, X): factor q of channel c at (q*C + c)*n
     for (int c = 0; c < C; c++) {
+        float *Adst = Ask + (size_t)c * 12 * ns;
+        if (fast) launch_skew_pack<float, float>(e.st, dA + (size_t)c * n, (long long)C * n, Adst, 12, sk);
+        else launch_skew_copy_n<float, float>(e.st, dA + (size_t)c * n, (long long)C * n, Adst, (long long)ns, 12, sk);
+        a.A[c] = Adst;
         launch_skew_copy_n<float, float>(e.st, dW + (size_t)c * n, 0, wsk + (size_t)c * ns, 0, 1, sk);
         a.weight[c] = wsk + (size_t)c * ns;
         a.a_data[c] = a_data[c];
@@ -1470,16 +1477,15 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     a.ax = alpha3[0] / (hx * hx);
     a.ay = alpha3[1] / (hy * hy);
     a.az = alpha3[2] / (hz * hz);
-    for (int d = 0; d < 3; d++) {
-        a.L[d] = Lb + (size_t)d * ns;
-        a.d[d] = db + (size_t)d * ns;
-    }
-    launch_laplace<float>(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lb, Lb + ns, Lb + 2 * ns);
+    launch_laplace<float>(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lnat, Lnat + n, Lnat + 2 * n, true);
+    if (fast) launch_skew_pack<float, float>(e.st, Lnat, (long long)n, Lb, 3, sk);
+    else launch_skew_copy_n<float, float>(e.st, Lnat, (long long)n, Lb, (long long)ns, 3, sk);
     FR3D_HIP(hipMemsetAsync(db, 0, ns * 3 * 4, e.st));
     a.iterations = iterations;
     a.update_lag = update_lag;
-    if (a_smooth == 1.0) {
+    if (fast) {
         launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
+        launch_unskew_unpack<float, float>(e.st, db, dn, (long long)n, 3, sk);
     } else {
         float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);
         SmoothArgs<float> sa;
@@ -1493,9 +1499,9 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
             for (int q = 0; q < 3; q++) sa.D[q][d] = smD + ((size_t)q * 3 + d) * ns;
         }
         sa.Ps = smP;
-        for (int q = 0; q < 9; q++) sa.M[q] = a.M[q];
+        for (int q = 0; q < 9; q++) sa.M[q] = Msk + (size_t)q * ns;
         for (int c = 0; c < C; c++) {
-            for (int q = 0; q < 12; q++) sa.A[q * FR3D_MAX_CHANNELS + c] = a.A[q * FR3D_MAX_CHANNELS + c];
+            for (int q = 0; q < 12; q++) sa.A[q * FR3D_MAX_CHANNELS + c] = Ask + ((size_t)c * 12 + q) * ns;
             sa.weight[c] = a.weight[c];
             sa.a_data[c] = a_data[c];
         }
@@ -1504,8 +1510,8 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
         launch_sor_smooth<float>(e.st, sa, e.sched(sk, iterations, SM_LAG));
         if (iterations > 0)
             FR3D_HIP(hipMemcpyAsync(db, sa.D[(iterations - 1) % 3][0], ns * 3 * 4, hipMemcpyDeviceToDevice, e.st));
+        launch_unskew_copy_n<float, float>(e.st, db, (long long)ns, dn, (long long)n, 3, sk);
     }
-    launch_unskew_copy_n<float, float>(e.st, db, (long long)ns, dn, (long long)n, 3, sk);
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 4, hipMemcpyDeviceToHost));
     FR3D_CATCH

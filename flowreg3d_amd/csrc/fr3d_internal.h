@@ -76,30 +76,36 @@ static inline Skew make_skew(int Z, int Y, int X)
     return k;
 }
 
-// Solver operands.  S is the storage type of everything the sweep streams: float (default) or
-// double (fr3d_params.solver_fp64 == 2, for configurations where the reference iteration itself is
-// ill-conditioned -- see DESIGN.md section 2).
+// Solver operands of the a_smooth == 1 sweep (k_sor.hip).  S is the storage type of everything the sweep
+// streams: float (default) or double (fr3d_params.solver_fp64 == 2, for configurations where the reference
+// iteration itself is ill-conditioned -- see DESIGN.md section 2).
+//
+// RECORD layout: the values of one voxel that are always used together sit next to each other (9 system
+// entries, 12 factors per channel, 3 Laplacian terms, 3 increments), records follow the skewed voxel order
+// above.  A wave then fetches a voxel's operands with 10 wide loads instead of 30 dword loads from 30
+// separate arrays, and a partly filled wave (rows of a hyperplane have every length from 1 to min(X,Y))
+// still moves long contiguous pieces: tools/microbench/row_layout.hip measures +18...+38 % useful bandwidth
+// for rows of 40...200 voxels against one array per operand.
 template <typename S>
 struct SorArgsT {
-    // frozen per-voxel system of the current psi window: M11,M22,M33,M12,M13,M23,b_u,b_v,b_w
+    // frozen per-voxel system of the current psi window, 9 per voxel: M11,M22,M33,M12,M13,M23,b_u,b_v,b_w
     // (written on psi-update iterations, read on the others; channels already summed)
-    S *M[9];
-    // square-root factors of the motion tensor, A[q*FR3D_MAX_CHANNELS + c], q = 4*k + a
-    // (k = x,y,z equation; a = u,v,w,t column): J = sum_k a_k a_k^T.  Read on psi-update iterations.
-    const S *A[12 * FR3D_MAX_CHANNELS];
-    const S *weight[FR3D_MAX_CHANNELS];
-    const S *L[3];  // alpha-weighted Laplacian of u,v,w (constant over the iterations)
-    S *d[3];        // du,dv,dw, updated in place
+    S *M;
+    // square-root factors of the motion tensor per channel, 12 per voxel, index 4*k + a (k = x,y,z equation;
+    // a = u,v,w,t column): J = sum_k a_k a_k^T.  Read on psi-update iterations.
+    const S *A[FR3D_MAX_CHANNELS];
+    const S *weight[FR3D_MAX_CHANNELS];  // one value per voxel (plain skewed arrays, shared by a batch)
+    const S *L;  // alpha-weighted Laplacian of u,v,w (constant over the iterations), 3 per voxel
+    S *d;        // du,dv,dw, 3 per voxel, updated in place
     Skew sk;
     double ax, ay, az;  // alpha/h^2
     double a_data[FR3D_MAX_CHANNELS];
     int C;
     int iterations, update_lag;
     // batch of volumes solved in lock step by the same launches: pointers above are volume 0,
-    // volume v adds v*stride elements (weights are shared by all volumes of a batch)
+    // volume v adds v*stride elements of S (weights are shared by all volumes of a batch)
     int nvol;
     long long vsM, vsA, vsL, vsD;
-    int dbg;  // measurement-only ablation bits (FR3D_SOR_DBG); 0 in production
 };
 using SorArgs = SorArgsT<float>;
 
@@ -171,6 +177,12 @@ void launch_skew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD 
 template <typename TS, typename TD>
 void launch_unskew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst,
                           long long dst_stride, int narr, const Skew &sk);
+// nrec (3 or 12) natural planar arrays, src_stride elements apart -> one skewed array of nrec-value records
+template <typename TS, typename TD>
+void launch_skew_pack(hipStream_t st, const TS *src, long long src_stride, TD *dst, int nrec, const Skew &sk);
+// skewed records of nrec (3) values -> nrec natural planar arrays, dst_stride elements apart
+template <typename TS, typename TD>
+void launch_unskew_unpack(hipStream_t st, const TS *src, TD *dst, long long dst_stride, int nrec, const Skew &sk);
 // natural = true writes L in the natural (Z,Y,X) layout instead of the skewed one
 template <typename TL>
 void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,

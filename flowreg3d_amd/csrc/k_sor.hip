@@ -32,7 +32,7 @@ namespace fr3d {
 #define SOR_BX 64
 #define SOR_BY_MAX 4  // rows of a tile = blockDim.y (1, 2 or 4; chosen per level, see sor_tile_rows)
 
-template <typename R, typename S, int C, typename I>
+template <typename R, typename S, int C>
 __global__ void __launch_bounds__(SOR_BX * SOR_BY_MAX)
 k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent,
            const int *__restrict__ lut)
@@ -60,39 +60,38 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
     const int i = r - j;
     if (r < 0 || j >= Y || i < 0) return;      // i < X holds by construction of jm0
 
-    // byte offsets (type I, see ldb) of the voxel and of its six neighbours inside one volume's array.
+    // voxel (record) indices of the voxel and of its six neighbours inside one volume's arrays.
     // A ghost neighbour holds the voxel's own old value (set_boundary_3d): a missing neighbour
-    // re-reads c0 (not yet overwritten), so all 21 increment loads are unconditional and go out
-    // together instead of hiding behind exec-mask branches that wait for du0.
-    const I esz = (I)sizeof(S);
-    const I c0 = (I)((long long)s * plane + (long long)k * Yp + jj) * esz;
-    const I pl = (I)plane * esz, row = (I)Yp * esz;
-    const I d1 = (I)(jm0 - sk_jm(X, r - 1)) * esz, d2 = (I)(jm0 - sk_jm(X, r + 1)) * esz;  // d2 <= 0: wraps, sums stay exact
-    S *const dU = a.d[0] + vol * a.vsD, *const dV = a.d[1] + vol * a.vsD, *const dW = a.d[2] + vol * a.vsD;
-    const bool nonb = a.dbg & 1;
-    const I xm = (i > 0 && !nonb) ? c0 - pl + d1 : c0;
-    const I xp = (i < X - 1 && !nonb) ? c0 + pl + d2 : c0;
-    const I ym = (j > 0 && !nonb) ? c0 - pl + d1 - esz : c0;
-    const I yp = (j < Y - 1 && !nonb) ? c0 + pl + d2 + esz : c0;
-    const I zm = (k > 0 && !nonb) ? c0 - pl - row : c0;
-    const I zp = (k < Z - 1 && !nonb) ? c0 + pl + row : c0;
-    const R du0 = (R)ldb(dU, c0), dv0 = (R)ldb(dV, c0), dw0 = (R)ldb(dW, c0);
-    const R su_x = (R)ldb(dU, xm) + (R)ldb(dU, xp), sv_x = (R)ldb(dV, xm) + (R)ldb(dV, xp),
-            sw_x = (R)ldb(dW, xm) + (R)ldb(dW, xp);
-    const R su_y = (R)ldb(dU, ym) + (R)ldb(dU, yp), sv_y = (R)ldb(dV, ym) + (R)ldb(dV, yp),
-            sw_y = (R)ldb(dW, ym) + (R)ldb(dW, yp);
-    const R su_z = (R)ldb(dU, zm) + (R)ldb(dU, zp), sv_z = (R)ldb(dV, zm) + (R)ldb(dV, zp),
-            sw_z = (R)ldb(dW, zm) + (R)ldb(dW, zp);
+    // re-reads c0 (not yet overwritten), so all seven increment records are loaded unconditionally and
+    // leave together instead of hiding behind exec-mask branches that wait for du0.
+    const long long c0 = (long long)s * plane + (long long)k * Yp + jj;
+    const int d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
+    S *const D = a.d + vol * a.vsD;
+    const long long xm = i > 0 ? c0 - plane + d1 : c0;
+    const long long xp = i < X - 1 ? c0 + plane + d2 : c0;
+    const long long ym = j > 0 ? c0 - plane + d1 - 1 : c0;
+    const long long yp = j < Y - 1 ? c0 + plane + d2 + 1 : c0;
+    const long long zm = k > 0 ? c0 - plane - Yp : c0;
+    const long long zp = k < Z - 1 ? c0 + plane + Yp : c0;
+    const Rec<S, 3> q0 = ldrec<S, 3>(D, c0);
+    const Rec<S, 3> qxm = ldrec<S, 3>(D, xm), qxp = ldrec<S, 3>(D, xp);
+    const Rec<S, 3> qym = ldrec<S, 3>(D, ym), qyp = ldrec<S, 3>(D, yp);
+    const Rec<S, 3> qzm = ldrec<S, 3>(D, zm), qzp = ldrec<S, 3>(D, zp);
+    const R du0 = (R)q0.v[0], dv0 = (R)q0.v[1], dw0 = (R)q0.v[2];
+    const R su_x = (R)qxm.v[0] + (R)qxp.v[0], sv_x = (R)qxm.v[1] + (R)qxp.v[1], sw_x = (R)qxm.v[2] + (R)qxp.v[2];
+    const R su_y = (R)qym.v[0] + (R)qyp.v[0], sv_y = (R)qym.v[1] + (R)qyp.v[1], sw_y = (R)qym.v[2] + (R)qyp.v[2];
+    const R su_z = (R)qzm.v[0] + (R)qzp.v[0], sv_z = (R)qzm.v[1] + (R)qzp.v[1], sw_z = (R)qzm.v[2] + (R)qzp.v[2];
     R m[9];
-    const bool upd = (t % a.update_lag) == 0 && !(a.dbg & 4);
-    sor_system<R, S, C, I>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
+    const bool upd = (t % a.update_lag) == 0;
+    sor_system<R, S, C>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
     R du1, dv1, dw1;
     sor_relax<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,
                  dw1);
-
-    stb(dU, c0, (S)du1);
-    stb(dV, c0, (S)dv1);
-    stb(dW, c0, (S)dw1);
+    Rec<S, 3> out;
+    out.v[0] = (S)du1;
+    out.v[1] = (S)dv1;
+    out.v[2] = (S)dw1;
+    strec<S, 3>(D, c0, out);
 }
 
 template <typename R, typename S>
@@ -100,13 +99,8 @@ static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo,
                         const SorEntry *ent, const int *lut, int by)
 {
     dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, by);
-    // 32-bit byte offsets whenever one volume's array stays below 4 GiB (every BASELINE size does)
-    const bool narrow = (unsigned long long)a.sk.total * sizeof(S) < (1ull << 32);
-#define FR3D_SOR_CASE(CH)                                                                                      \
-    case CH:                                                                                                   \
-        if (narrow) hipLaunchKernelGGL((k_sor_step<R, S, CH, unsigned>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut); \
-        else hipLaunchKernelGGL((k_sor_step<R, S, CH, size_t>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut);     \
-        break;
+#define FR3D_SOR_CASE(CH)                                                                                  \
+    case CH: hipLaunchKernelGGL((k_sor_step<R, S, CH>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut); break;
     switch (a.C) {
         FR3D_SOR_CASE(1)
         FR3D_SOR_CASE(2)
@@ -116,8 +110,7 @@ static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo,
         // (the loop already handles one channel at a time, k_sor_core.h; level_solver_3d.py:356-377 loops over any C)
         default:
             FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
-            if (narrow) hipLaunchKernelGGL((k_sor_step<R, S, 0, unsigned>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut);
-            else hipLaunchKernelGGL((k_sor_step<R, S, 0, size_t>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut);
+            hipLaunchKernelGGL((k_sor_step<R, S, 0>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut);
             break;
     }
 #undef FR3D_SOR_CASE
@@ -249,9 +242,7 @@ void free_sor_schedule(SorSched &s)
 template <typename S>
 long long launch_sor(hipStream_t st, const SorArgsT<S> &a_in, bool fp64, const SorSched &sc)
 {
-    SorArgsT<S> a = a_in;
-    static const char *dbg_env = getenv("FR3D_SOR_DBG");
-    a.dbg = dbg_env ? atoi(dbg_env) : 0;
+    const SorArgsT<S> &a = a_in;
     long long launches = 0;
     for (size_t l = 0; l < sc.tau.size(); l++) {
         if (sc.ntiles[l] <= 0) continue;
@@ -357,6 +348,97 @@ template void launch_skew_copy_n<float, double>(hipStream_t, const float *, long
 template void launch_skew_copy_n<double, double>(hipStream_t, const double *, long long, double *, long long, int, const Skew &);
 template void launch_unskew_copy_n<float, float>(hipStream_t, const float *, long long, float *, long long, int, const Skew &);
 template void launch_unskew_copy_n<double, float>(hipStream_t, const double *, long long, float *, long long, int, const Skew &);
+
+// NREC natural planar arrays -> one skewed array of NREC-value records (and back), through an LDS tile of
+// TY x 32 voxels of one z-slice: the natural side moves as 128-B row segments, the skewed side as whole records
+// along the tile's anti-diagonals (x+y constant => same hyperplane and row, consecutive j => consecutive
+// records), so both sides are coalesced.
+#define PKX 32
+template <typename TS, typename TD, int NREC, int TY>
+__global__ void __launch_bounds__(256)
+k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ dst, int Z, int Y, int X, int Yp,
+            long long plane, int to_skew)
+{
+    // pitch 34: element (ly, d - ly) of a diagonal sits at 33*ly + d -> consecutive banks for consecutive ly
+    __shared__ TD tile[NREC][TY][PKX + 2];
+    const int txn = (X + PKX - 1) / PKX;
+    const int x0 = (blockIdx.x % txn) * PKX, y0 = (blockIdx.x / txn) * TY;
+    const int z = blockIdx.y;
+    const int lane = threadIdx.x % PKX, grp = threadIdx.x / PKX;  // 8 groups of 32
+    constexpr int ND = TY + PKX - 1;                               // anti-diagonals of the tile
+    if (to_skew) {
+#pragma unroll
+        for (int a = 0; a < NREC; a++) {
+            TS v[(TY + 7) / 8];
+#pragma unroll
+            for (int q = 0; q < (TY + 7) / 8; q++) {
+                const int ly = grp + 8 * q, y = y0 + ly, x = x0 + lane;
+                v[q] = (ly < TY && y < Y && x < X) ? src[a * src_stride + ((size_t)z * Y + y) * X + x] : (TS)0;
+            }
+#pragma unroll
+            for (int q = 0; q < (TY + 7) / 8; q++)
+                if (grp + 8 * q < TY) tile[a][grp + 8 * q][lane] = (TD)v[q];
+        }
+        __syncthreads();
+        for (int d = grp; d < ND; d += 8) {
+            const int ly = lane, lx = d - lane;
+            const int y = y0 + ly, x = x0 + lx;
+            if (ly < TY && lx >= 0 && lx < PKX && y < Y && x < X) {
+                TD *o = dst + (size_t)sk_index(X, Yp, plane, z, y, x) * NREC;
+#pragma unroll
+                for (int a = 0; a < NREC; a++) o[a] = tile[a][ly][lx];
+            }
+        }
+    } else {
+        for (int d = grp; d < ND; d += 8) {
+            const int ly = lane, lx = d - lane;
+            const int y = y0 + ly, x = x0 + lx;
+            if (ly < TY && lx >= 0 && lx < PKX && y < Y && x < X) {
+                const TS *o = src + (size_t)sk_index(X, Yp, plane, z, y, x) * NREC;
+#pragma unroll
+                for (int a = 0; a < NREC; a++) tile[a][ly][lx] = (TD)o[a];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < NREC; a++)
+#pragma unroll
+            for (int q = 0; q < (TY + 7) / 8; q++) {
+                const int ly = grp + 8 * q, y = y0 + ly, x = x0 + lane;
+                if (ly < TY && y < Y && x < X) dst[a * src_stride + ((size_t)z * Y + y) * X + x] = tile[a][ly][lane];
+            }
+    }
+}
+
+template <typename TS, typename TD, int NREC>
+static void launch_pack_t(hipStream_t st, const TS *src, long long stride, TD *dst, const Skew &sk, int to_skew)
+{
+    // LDS per workgroup: NREC * TY * 34 values; 12 fp64 values per voxel need the 16-row tile
+    constexpr int TY = (sizeof(TD) * NREC > 48) ? 16 : 32;
+    FR3D_CHECK(sk.Z <= 65535, "skew transposes: z axis longer than 65535");
+    dim3 grid(cdiv(sk.X, PKX) * cdiv(sk.Y, TY), sk.Z);
+    hipLaunchKernelGGL((k_skew_pack<TS, TD, NREC, TY>), grid, dim3(256), 0, st, src, stride, dst, sk.Z, sk.Y, sk.X, sk.Yp,
+                       sk.plane, to_skew);
+    FR3D_LAUNCH_CHECK();
+}
+
+template <typename TS, typename TD>
+void launch_skew_pack(hipStream_t st, const TS *src, long long src_stride, TD *dst, int nrec, const Skew &sk)
+{
+    if (nrec == 3) launch_pack_t<TS, TD, 3>(st, src, src_stride, dst, sk, 1);
+    else if (nrec == 12) launch_pack_t<TS, TD, 12>(st, src, src_stride, dst, sk, 1);
+    else throw Error("internal: records of 3 or 12 values");
+}
+template <typename TS, typename TD>
+void launch_unskew_unpack(hipStream_t st, const TS *src, TD *dst, long long dst_stride, int nrec, const Skew &sk)
+{
+    if (nrec == 3) launch_pack_t<TS, TD, 3>(st, src, dst_stride, dst, sk, 0);
+    else throw Error("internal: records of 3 values");
+}
+template void launch_skew_pack<float, float>(hipStream_t, const float *, long long, float *, int, const Skew &);
+template void launch_skew_pack<double, double>(hipStream_t, const double *, long long, double *, int, const Skew &);
+template void launch_unskew_unpack<float, float>(hipStream_t, const float *, float *, long long, int, const Skew &);
+template void launch_unskew_unpack<double, float>(hipStream_t, const double *, float *, long long, int, const Skew &);
 
 // L = ax*(u_ip + u_im - 2u) + ay*(...) + az*(...) with edge-padded u (add_boundary,
 // core/optical_flow_3d.py:88), evaluated in fp64 from the fp32-exact level flow.

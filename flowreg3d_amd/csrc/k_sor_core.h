@@ -13,29 +13,32 @@ template <typename R> __device__ __forceinline__ R fma_(R a, R b, R c);
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
 
-// Element access by BYTE offset of type I: `unsigned` when one volume's array is below 4 GiB (the
-// load then takes the scalar-base + 32-bit vector-offset form and the 64-bit per-lane address
-// arithmetic disappears), `size_t` otherwise.
-template <typename S, typename I>
-__device__ __forceinline__ S ldb(const S *base, I off)
+// A record of N consecutive values of one voxel; loading it as one object lets the compiler emit wide
+// global loads (dwordx3 / dwordx4) instead of N dword loads.
+template <typename S, int N>
+struct Rec {
+    S v[N];
+};
+template <typename S, int N>
+__device__ __forceinline__ Rec<S, N> ldrec(const S *base, long long voxel)
 {
-    return *reinterpret_cast<const S *>(reinterpret_cast<const char *>(base) + off);
+    return *reinterpret_cast<const Rec<S, N> *>(base + voxel * N);
 }
-template <typename S, typename I>
-__device__ __forceinline__ void stb(S *base, I off, S v)
+template <typename S, int N>
+__device__ __forceinline__ void strec(S *base, long long voxel, const Rec<S, N> &r)
 {
-    *reinterpret_cast<S *>(reinterpret_cast<char *>(base) + off) = v;
+    *reinterpret_cast<Rec<S, N> *>(base + voxel * N) = r;
 }
 
 // The 3x3 system of one voxel for the current psi window: m[0..5] = M11,M22,M33,M12,M13,M23 with
 // M = sum_c w_c psi_c J_c, m[6..8] = b = L - sum_c w_c psi_c (J14,J24,J34)_c.  psi is frozen between
 // psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration (`upd`)
 // builds them from the square-root factors and, when `store`, writes them; the other iterations
-// stream the 9 stored values -- independent of the channel count.  `e` is the voxel's byte
-// offset inside one volume's array, vM/vA/vL the (wave-uniform) element offsets of the volume's slab.
-template <typename R, typename S, int C, typename I>
+// stream the 9 stored values -- independent of the channel count.  `e` is the voxel's index inside one
+// volume's arrays, vM/vA/vL the (wave-uniform) element offsets of the volume's slab.
+template <typename R, typename S, int C>
 __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool store, long long vM, long long vA,
-                                           long long vL, I e, R du0, R dv0, R dw0, R (&m)[9])
+                                           long long vL, long long e, R du0, R dv0, R dw0, R (&m)[9])
 {
     if (upd) {
         R M11 = 0, M22 = 0, M33 = 0, M12 = 0, M13 = 0, M23 = 0, bu = 0, bv = 0, bw = 0;
@@ -48,10 +51,9 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
             // The quadratic form is evaluated as the sum of three squared residuals of the tensor's
             // square-root factors (see k_tensor.hip) -- algebraically the reference's expression,
             // but stable with fp32 storage.
-            S f[12];
-#pragma unroll
-            for (int q = 0; q < 12; q++) f[q] = ldb(a.A[q * FR3D_MAX_CHANNELS + c] + vA, e);
-            double wt = (double)ldb(a.weight[c], e);
+            const Rec<S, 12> fr = ldrec<S, 12>(a.A[c] + vA, e);
+            const S *f = fr.v;
+            double wt = (double)a.weight[c][e];
             const double adc = a.a_data[c];
             if (adc != 1.0) {
                 const double u_ = (double)du0, v_ = (double)dv0, w_ = (double)dw0;
@@ -81,21 +83,22 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
             bv = fma_<R>(w, fma_<R>(z1, z3, fma_<R>(y1, y3, x1 * x3)), bv);
             bw = fma_<R>(w, fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3)), bw);
         }
-        const R b_u = (R)ldb(a.L[0] + vL, e) - bu;
-        const R b_v = (R)ldb(a.L[1] + vL, e) - bv;
-        const R b_w = (R)ldb(a.L[2] + vL, e) - bw;
-        if (store) {
-            stb(a.M[0] + vM, e, (S)M11); stb(a.M[1] + vM, e, (S)M22); stb(a.M[2] + vM, e, (S)M33);
-            stb(a.M[3] + vM, e, (S)M12); stb(a.M[4] + vM, e, (S)M13); stb(a.M[5] + vM, e, (S)M23);
-            stb(a.M[6] + vM, e, (S)b_u); stb(a.M[7] + vM, e, (S)b_v); stb(a.M[8] + vM, e, (S)b_w);
-        }
+        const Rec<S, 3> lr = ldrec<S, 3>(a.L + vL, e);
+        const R b_u = (R)lr.v[0] - bu;
+        const R b_v = (R)lr.v[1] - bv;
+        const R b_w = (R)lr.v[2] - bw;
+        Rec<S, 9> mr;
+        mr.v[0] = (S)M11; mr.v[1] = (S)M22; mr.v[2] = (S)M33;
+        mr.v[3] = (S)M12; mr.v[4] = (S)M13; mr.v[5] = (S)M23;
+        mr.v[6] = (S)b_u; mr.v[7] = (S)b_v; mr.v[8] = (S)b_w;
+        if (store) strec<S, 9>(a.M + vM, e, mr);
         // use the stored (rounded) values so update and non-update iterations see one system
-        m[0] = (R)(S)M11; m[1] = (R)(S)M22; m[2] = (R)(S)M33;
-        m[3] = (R)(S)M12; m[4] = (R)(S)M13; m[5] = (R)(S)M23;
-        m[6] = (R)(S)b_u; m[7] = (R)(S)b_v; m[8] = (R)(S)b_w;
-    } else {
 #pragma unroll
-        for (int q = 0; q < 9; q++) m[q] = (R)ldb(a.M[q] + vM, e);
+        for (int q = 0; q < 9; q++) m[q] = (R)mr.v[q];
+    } else {
+        const Rec<S, 9> mr = ldrec<S, 9>(a.M + vM, e);
+#pragma unroll
+        for (int q = 0; q < 9; q++) m[q] = (R)mr.v[q];
     }
 }
 

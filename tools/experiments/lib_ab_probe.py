@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""A/B of two builds of the engine (FR3D_LIB selects the shared library; one process per build, alternated):
+SOR time per volume and the whole step.  usage (GPU box): python tools/experiments/lib_ab_probe.py EDGE BATCH LIB_A LIB_B [reps]"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CHILD = r"""
+import ctypes as C, json, os, sys, time
+sys.path.insert(0, %r)
+from flowreg3d_amd import _lib
+from flowreg3d_amd.synthetic import fast_pair
+n, nb = int(sys.argv[1]), int(sys.argv[2])
+lib = _lib.init(0)
+levels = {64: 2, 128: 3, 256: 4, 512: 5}[n]
+fixed, moving, _ = fast_pair((n, n, n))
+nv = n ** 3
+params = _lib.make_params(alpha=(0.25,) * 3, update_lag=5, iterations=100, min_level=0, levels=levels, eta=0.8,
+                          a_smooth=1.0, a_data=0.45, n_channels=1, solver_fp64=1)
+ref = lib.fr3d_dev_malloc(nv * 4); mov = lib.fr3d_dev_malloc(nv * 4 * nb)
+flows = lib.fr3d_dev_malloc(nv * 12 * nb); regs = lib.fr3d_dev_malloc(nv * 4 * nb)
+lib.fr3d_h2d(ref, fixed.ctypes.data, nv * 4)
+for b in range(nb):
+    lib.fr3d_h2d(mov + b * nv * 4, moving.ctypes.data, nv * 4)
+lib.fr3d_set_batch(nb)
+def run(prof):
+    lib.fr3d_prof_enable(1 if prof else 0)
+    if prof: lib.fr3d_prof_reset()
+    _lib.check(lib.fr3d_process_batch_dev(C.byref(params), mov, mov, ref, ref, None, None, nb, n, n, n, 1, 3, flows, regs,
+                                          C.cast(None, _lib.PROGRESS_FN), None))
+    lib.fr3d_sync()
+t0 = time.time()
+while time.time() - t0 < 10: run(False)
+best = None
+for _ in range(3):
+    t0 = time.perf_counter(); run(True); wall = time.perf_counter() - t0
+    s = _lib.prof_get()
+    r = {"sor_ms_per_vol": round(s["sor"]["ms"] / nb, 2), "frac": round(s["sor"]["algo_bytes"] / s["sor"]["ms"] / 8e9, 4),
+         "tensor_ms": round(s["tensor"]["ms"] / nb, 2), "other_ms": round(s["other"]["ms"] / nb, 2), "wall_ms_per_vol": round(1e3 * wall / nb, 1)}
+    if best is None or r["wall_ms_per_vol"] < best["wall_ms_per_vol"]: best = r
+import hashlib, numpy as np
+out = np.empty((n, n, n, 3), np.float32); lib.fr3d_d2h(out.ctypes.data, flows, nv * 12)
+best["flow_sha"] = hashlib.sha256(out.tobytes()).hexdigest()[:12]
+print(json.dumps(best))
+""" % ROOT
+
+
+def main():
+    n, nb, la, lb = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+    reps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+    for rep in range(reps):
+        for tag, lib in (("A", la), ("B", lb)):
+            env = dict(os.environ, FR3D_LIB=os.path.abspath(lib))
+            r = subprocess.run([sys.executable, "-c", CHILD, n, nb], env=env, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            print(json.dumps({"edge": int(n), "batch": int(nb), "lib": tag + ":" + os.path.basename(lib), "rep": rep,
+                              **(json.loads(line[-1]) if line else {"error": r.stderr[-300:]})}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
