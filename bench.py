@@ -150,6 +150,20 @@ def cpu_baseline(workload, sample_edge):
             "sample_volumes_per_sec_all_cores": rate_all, "host_cpus": os.cpu_count()}
 
 
+SOLVER_NAMES = ("fp32 storage, fp32 update arithmetic", "fp32 storage, fp64 update arithmetic",
+                "fp64 storage and arithmetic")
+# mean flow end-point error against the CPU path at full size, measured by tests/test_gpu_fullsize_parity.py against
+# tests/golden/fullsize_*.npz (a property of the solver mode, not re-measured by a bench run)
+PARITY = {("cfg2", 1): 5.7e-5, ("cfg3", 1): 1.5e-4, ("cfg3", 2): 1.2e-5}
+
+
+def resolved_mode(solver_fp64, nvox, channels=1):
+    """FR3D_SOLVER_AUTO as the engine resolves it (flowreg3d_amd/csrc/engine.hip: solver_mode)."""
+    if solver_fp64 >= 0:
+        return solver_fp64
+    return 2 if (channels >= 2 or nvox > (1 << 25)) else 1
+
+
 def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, world, dist, dev_index, fast_inputs):
     """Warm up, condition, time EXACTLY K steps (volumes per rank) of `workload`; -> dict of results.
     Inputs are generated once and are resident in HBM before the timed region starts."""
@@ -157,7 +171,8 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
     Z, Y, X, levels, desc = WORKLOADS[workload]
     nv = Z * Y * X
     T = K + W
-    params = _lib.make_params(n_channels=1, solver_fp64=solver_fp64, **solver_kwargs(levels))
+    params = _lib.make_params(n_channels=1, solver_fp64=None if solver_fp64 < 0 else solver_fp64, **solver_kwargs(levels))
+    mode = resolved_mode(solver_fp64, nv)
 
     def reference_volume():
         # texture(): blurred noise + blobs; fast_pair's O(N) stand-in where the 512^3 blur would
@@ -192,7 +207,8 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
                                      batch.ptr + i * nv * 4))
     gflow.free()
 
-    batch_vols = max(1, min(K, batch_arg if batch_arg > 0 else (4 if workload == "cfg3" else 8)))
+    # default lock-step batch: 8; at 512^3 4 slabs of solver operands (43 GB each, fp32 storage) or 2 (86 GB, fp64)
+    batch_vols = max(1, min(K, batch_arg if batch_arg > 0 else ((2 if mode == 2 else 4) if workload == "cfg3" else 8)))
     lib.fr3d_set_batch(batch_vols)  # warm-up and timed run use the same lock-step batch / workspace
 
     def run(first, count, prof):
@@ -236,7 +252,8 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
         tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    res = {"elapsed": elapsed, "stats": stats, "batch_vols": batch_vols, "desc": desc}
+    res = {"elapsed": elapsed, "stats": stats, "batch_vols": batch_vols, "desc": desc, "mode": mode,
+           "parity_mean_epe_vs_cpu": PARITY.get((workload, mode))}
     if rank == 0:
         sor = stats["sor"]
         achieved = sor["algo_bytes"] / (sor["ms"] * 1e-3) / 1e9 if sor["ms"] > 0 else 0.0
@@ -248,13 +265,14 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 pj = json.load(fh)
             pmc = pj.get(workload)
-            if pmc:
+            if pmc and mode < 2:
                 traffic = pmc["bytes_per_update"] * sor["units"] / max(sor["launches"], 1)
                 traffic_source = f"profiles/pmc_traffic.json ({pj.get('_taken_at', 'round 1, commit 0249743')}): " \
                                  f"{pmc['bytes_per_update']:.1f} B per voxel update x this run's updates per launch"
         except (OSError, ValueError, KeyError):
             traffic = None
         res["roofline"] = {"bound": "hbm", "kernel": "k_sor_step (SOR hyperplane sweep)",
+                           "algo_bytes_per_update": sor["algo_bytes"] / max(sor["units"], 1),
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                            "algo_bytes_per_launch": sor["algo_bytes"] / max(sor["launches"], 1),
@@ -306,9 +324,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra legs of the default run (host-array path, the 512^3 line)")
-    ap.add_argument("--solver-fp64", type=int, default=1, choices=(0, 1, 2),
-                    help="0 fp32 storage+update, 1 fp32 storage with fp64 update arithmetic (default = the library's "
-                         "choice for one channel; same speed as 0), 2 fp64 storage (parity-grade, 2x the bytes)")
+    ap.add_argument("--solver-fp64", type=int, default=-1, choices=(-1, 0, 1, 2),
+                    help="-1 = the library's choice (FR3D_SOLVER_AUTO: fp32 storage with fp64 update arithmetic up to 2^25 "
+                         "voxels, fp64 storage beyond -- the cheapest mode measured to stay within 1e-4 voxels of the CPU "
+                         "path); 0 fp32 storage+update, 1 fp32 storage with fp64 update arithmetic, 2 fp64 storage")
     ap.add_argument("--batch", type=int, default=0,
                     help="volumes solved in lock step per GPU (shared launches); 0 = 8, or 4 at 512^3 "
                          "where 8 slabs of solver operands (43 GB each) would not fit in 288 GB")
@@ -362,8 +381,6 @@ def main():
         _lib.check(lib.fr3d_read_probe(1 << 26, 20, C.byref(rstream)))
         m["roofline"].update(stream_measured=round(stream.value, 1), read_stream_measured=round(rstream.value, 1),
                              frac_of_stream_measured=round(achieved / stream.value, 4) if stream.value > 0 else None)
-        solver_names = ("fp32 storage, fp32 update arithmetic", "fp32 storage, fp64 update arithmetic",
-                        "fp64 storage and arithmetic")
         out = {
             "metric": "volumes/sec (3D flow solve + warp)",
             "value": (K * world) / elapsed,
@@ -375,11 +392,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.solver_fp64 < 2 else "f64",
+            "dtype": "f32" if m["mode"] < 2 else "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {m['desc']}; iterations=100, update_lag=5, eta=0.8, "
                                    "alpha=0.25, a_data=0.45, a_smooth=1; lexicographic-exact SOR",
-                       "solver": solver_names[args.solver_fp64],
+                       "solver": SOLVER_NAMES[m["mode"]] + (" (library's automatic choice)" if args.solver_fp64 < 0 else ""),
+                       "parity_mean_epe_vs_cpu_path": m["parity_mean_epe_vs_cpu"],
                        "volumes_per_gpu_per_step": 1, "lockstep_batch": m["batch_vols"],
                        "untimed_conditioning_s": args.condition if W > 0 else 0.0,
                        "sharding": f"volume-per-GPU x{world}",
@@ -392,17 +410,22 @@ def main():
         }
         if world == 1 and not args.no_extras and args.workload == "cfg2":
             # (1) the host-array entry (PCIe both ways) -- reported beside `value`, never as `value`
-            out["host_path"] = host_path("cfg2", 8, args.solver_fp64)
-            # (2) the 512^3 configuration the roofline target is stated on: workspace of the 256^3 run is
-            # released first (8 slabs of 5.4 GB + 4 slabs of 43 GB would not fit next to each other)
-            _lib.shutdown()
-            lib = _lib.init(dev_index)
-            c3 = measure(lib, _lib, "cfg3", 4, 1, 4, 8.0, args.solver_fp64, 0, 1, None, dev_index, fast_inputs=True)
-            out["cfg3"] = {"workload": f"cfg3: {c3['desc']}; same solver parameters", "value": 4 / c3["elapsed"],
-                           "unit": "volumes/sec", "steps": 4, "warmup": 1, "ms_per_step": 1e3 * c3["elapsed"] / 4,
-                           "lockstep_batch": c3["batch_vols"], "untimed_conditioning_s": 8.0,
-                           "solver": solver_names[args.solver_fp64], "roofline": c3["roofline"],
-                           "kernel_ms_per_step": c3["kernel_ms_per_step"], "roofline_stages": c3["roofline_stages"]}
+            out["host_path"] = host_path("cfg2", 8, None if args.solver_fp64 < 0 else args.solver_fp64)
+            # (2) the 512^3 configuration the roofline target is stated on, in both storage modes: fp64 storage is what
+            # the library chooses there (mean EPE 1.2e-5 against the CPU path; fp32 storage measures 1.5e-4, above
+            # the 1e-4 bound) and fp32 storage is the mode the 76 B / update roofline figure is defined on.
+            # The workspace of the 256^3 run is released first.
+            for key, md, cond in (("cfg3", -1, 8.0), ("cfg3_fp32_storage", 1, 6.0)):
+                _lib.shutdown()
+                lib = _lib.init(dev_index)
+                c3 = measure(lib, _lib, "cfg3", 4, 1, 0, cond, md, 0, 1, None, dev_index, fast_inputs=True)
+                out[key] = {"workload": f"cfg3: {c3['desc']}; same solver parameters", "value": 4 / c3["elapsed"],
+                            "unit": "volumes/sec", "steps": 4, "warmup": 1, "ms_per_step": 1e3 * c3["elapsed"] / 4,
+                            "lockstep_batch": c3["batch_vols"], "untimed_conditioning_s": cond,
+                            "dtype": "f32" if c3["mode"] < 2 else "f64",
+                            "solver": SOLVER_NAMES[c3["mode"]] + (" (library's automatic choice)" if md < 0 else " (forced)"),
+                            "parity_mean_epe_vs_cpu_path": c3["parity_mean_epe_vs_cpu"], "roofline": c3["roofline"],
+                            "kernel_ms_per_step": c3["kernel_ms_per_step"], "roofline_stages": c3["roofline_stages"]}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

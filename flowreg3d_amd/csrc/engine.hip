@@ -223,8 +223,8 @@ struct Engine {
     {
         auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, lag);
         auto it = scheds.find(key);
-        if (it == scheds.end())
-            it = scheds.emplace(key, build_sor_schedule(sk, iterations, sor_tile_rows(sk), lag)).first;
+        if (it == scheds.end())  // the lag-4 (a_smooth != 1) kernels are written for 64 x 4 workgroups
+            it = scheds.emplace(key, build_sor_schedule(sk, iterations, lag == 2 ? sor_tile_rows(sk) : 4, lag)).first;
         return it->second;
     }
     // profiling
@@ -516,7 +516,9 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         if (p.a_smooth == 1.0) {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
             long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
-            sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
+            // algorithmic traffic of the reference's update: 9C tensor entries + C (w psi) + 3 L + 3 d read, 3 d written,
+            // in the solver's storage type: 4 (10C + 9) B with fp32 storage, twice that with fp64 storage
+            sp.add((double)sizeof(S) * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
         } else {
             // a_smooth != 1 (k_sor_smooth.hip): psi_smooth every iteration, triple-buffered increments,
             // one volume at a time; the result is copied into the batch slab the common tail reads
@@ -552,7 +554,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 if (p.iterations > 0)
                     FR3D_HIP(hipMemcpyAsync(dbuf + (size_t)b * a.vsD, sa.D[(p.iterations - 1) % 3][0], ns * 3 * sizeof(S),
                                             hipMemcpyDeviceToDevice, e.st));
-                sp.add(4.0 * (10.0 * C + 9.0) * (double)nl * p.iterations, n, (long long)nl * p.iterations);
+                sp.add((double)sizeof(S) * (10.0 * C + 9.0) * (double)nl * p.iterations, n, (long long)nl * p.iterations);
             }
         }
         // increments back to the natural layout, 5^3 median (:517-526), accumulate (:527-529)
@@ -597,18 +599,27 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
     }
 }
 
-// FR3D_SOLVER_AUTO: one channel -> fp32 storage with fp64 update arithmetic (the sweep is memory-bound,
-// so the wider arithmetic is free, and it removes a quarter of the rounding error); several channels ->
-// fp64 storage, because the reference iteration itself amplifies rounding there
-// and only that stays below the 1e-4 bound
-static int solver_mode(const fr3d_params &p, int C) { return p.solver_fp64 < 0 ? (C >= 2 ? 2 : 1) : p.solver_fp64; }
+// FR3D_SOLVER_AUTO picks the cheapest mode that keeps the flow within 1e-4 voxels (mean end-point error) of the
+// reference CPU path, as measured against full CPU runs (tests/test_gpu_fullsize_parity.py):
+//  * one channel, up to 2^25 voxels (256^3 = 2^24: 5.7e-5): fp32 storage with fp64 update arithmetic -- the
+//    sweep is memory-bound, so the wider arithmetic is free;
+//  * one channel, larger volumes (512^3: 1.5e-4 with fp32 storage, 1.2e-5 with fp64 storage): fp64 storage --
+//    increments, frozen system and factors each cost ~1e-4 there when held in fp32
+//    (profiles/r02/numerics_512_rounding_groups.md);
+//  * several channels: fp64 storage, the reference iteration itself amplifies rounding there.
+static int solver_mode(const fr3d_params &p, int C, long long nvox)
+{
+    if (p.solver_fp64 >= 0) return p.solver_fp64;
+    return (C >= 2 || nvox > (1LL << 25)) ? 2 : 1;
+}
 
 static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std::vector<Level> &lv, int min_level,
                                   const RefPyramid &rp, int nb, const float *const *moving, int Z, int Y, int X,
                                   int C, const float *uvw_init, float *const *flow_out, int reserve_nb = 1)
 {
     fr3d_params p = p_in;
-    p.solver_fp64 = solver_mode(p_in, C);
+    p.solver_fp64 = solver_mode(p_in, C, (long long)Z * Y * X);
+    FR3D_CHECK(p.solver_fp64 >= 0 && p.solver_fp64 <= 2, "solver_fp64 must be FR3D_SOLVER_AUTO, 0, 1 or 2");
     if (p.solver_fp64 == 2)
         get_displacement_core_t<double>(e, p, lv, min_level, rp, nb, moving, Z, Y, X, C, uvw_init, flow_out, reserve_nb);
     else
@@ -777,7 +788,7 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     if (!rp_in) build_ref_pyramid(e, lv, ref_proc, weight, Z, Y, X, C, rp_own, "pb_");
     const RefPyramid &rp = rp_in ? *rp_in : rp_own;
     const size_t nv = (size_t)Z * Y * X;
-    g_fp64_storage = solver_mode(*p, C) == 2;
+    g_fp64_storage = solver_mode(*p, C, (long long)Z * Y * X) == 2;
     const int B = T > 0 ? pick_batch(T, lv, C) : 1;
     // T volumes in ceil(T/B) lock-step batches of (nearly) equal size: 10 volumes at B = 4 run as
     // 4+3+3, not 4+4+2 (the shared launches amortise best over evenly filled batches)

@@ -106,6 +106,9 @@ struct SorArgsT {
     // volume v adds v*stride elements of S (weights are shared by all volumes of a batch)
     int nvol;
     long long vsM, vsA, vsL, vsD;
+    // numerics experiments (FR3D_SOR_DBG, meaningful with S = double): round to fp32 when stored / read --
+    // 1 increments, 2 frozen system, 4 Laplacian terms, 8 factors (profiles/r02/numerics_512_rounding_groups.md)
+    int dbg;
 };
 using SorArgs = SorArgsT<float>;
 
@@ -214,8 +217,7 @@ struct SorSched {
     int *bnd_meta = nullptr;                         // device, (first, count) per hyperplane
     int bnd_max = 0;                                 // largest bnd_count
 };
-// Tile = 64 lanes along j x `by` rows.  Measured on MI355X: 4 rows at every level size (1 and 2 rows
-// are within 2 % since the neighbour loads became unconditional); FR3D_SOR_BY overrides.
+// Tile = 64 lanes along j x `by` rows (2 by default; FR3D_SOR_BY overrides).
 int sor_tile_rows(const Skew &sk);
 // iteration t works on hyperplane tau - lag*t in launch tau (lag 2: a_smooth == 1 kernel; lag 4 = SM_LAG:
 // the a_smooth != 1 kernels, whose P-stage and sweep share one schedule two launches apart)

@@ -91,6 +91,7 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
     out.v[0] = (S)du1;
     out.v[1] = (S)dv1;
     out.v[2] = (S)dw1;
+    if (a.dbg & 1) { out.v[0] = (S)(float)du1; out.v[1] = (S)(float)dv1; out.v[2] = (S)(float)dw1; }
     strec<S, 3>(D, c0, out);
 }
 
@@ -125,7 +126,7 @@ int sor_tile_rows(const Skew &sk)
         if (v == 1 || v == 2 || v == 4) return v;
     }
     (void)sk;
-    return 4;
+    return 2;  // 64 lanes x 2 rows: 1-2 % ahead of 4 rows at 256^3 and 512^3 with the record layout (1 row: -1 %)
 }
 
 SorSched build_sor_schedule(const Skew &sk, int T, int by, int lag)
@@ -242,7 +243,9 @@ void free_sor_schedule(SorSched &s)
 template <typename S>
 long long launch_sor(hipStream_t st, const SorArgsT<S> &a_in, bool fp64, const SorSched &sc)
 {
-    const SorArgsT<S> &a = a_in;
+    SorArgsT<S> a = a_in;
+    const char *dbg_env = getenv("FR3D_SOR_DBG");  // numerics experiments, see SorArgsT::dbg
+    a.dbg = dbg_env ? atoi(dbg_env) : 0;
     long long launches = 0;
     for (size_t l = 0; l < sc.tau.size(); l++) {
         if (sc.ntiles[l] <= 0) continue;

@@ -51,7 +51,11 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
             // The quadratic form is evaluated as the sum of three squared residuals of the tensor's
             // square-root factors (see k_tensor.hip) -- algebraically the reference's expression,
             // but stable with fp32 storage.
-            const Rec<S, 12> fr = ldrec<S, 12>(a.A[c] + vA, e);
+            Rec<S, 12> fr = ldrec<S, 12>(a.A[c] + vA, e);
+            if (a.dbg & 8) {
+#pragma unroll
+                for (int q = 0; q < 12; q++) fr.v[q] = (S)(float)fr.v[q];
+            }
             const S *f = fr.v;
             double wt = (double)a.weight[c][e];
             const double adc = a.a_data[c];
@@ -83,7 +87,8 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
             bv = fma_<R>(w, fma_<R>(z1, z3, fma_<R>(y1, y3, x1 * x3)), bv);
             bw = fma_<R>(w, fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3)), bw);
         }
-        const Rec<S, 3> lr = ldrec<S, 3>(a.L + vL, e);
+        Rec<S, 3> lr = ldrec<S, 3>(a.L + vL, e);
+        if (a.dbg & 4) { lr.v[0] = (S)(float)lr.v[0]; lr.v[1] = (S)(float)lr.v[1]; lr.v[2] = (S)(float)lr.v[2]; }
         const R b_u = (R)lr.v[0] - bu;
         const R b_v = (R)lr.v[1] - bv;
         const R b_w = (R)lr.v[2] - bw;
@@ -91,6 +96,10 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
         mr.v[0] = (S)M11; mr.v[1] = (S)M22; mr.v[2] = (S)M33;
         mr.v[3] = (S)M12; mr.v[4] = (S)M13; mr.v[5] = (S)M23;
         mr.v[6] = (S)b_u; mr.v[7] = (S)b_v; mr.v[8] = (S)b_w;
+        if (a.dbg & 2) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) mr.v[q] = (S)(float)mr.v[q];
+        }
         if (store) strec<S, 9>(a.M + vM, e, mr);
         // use the stored (rounded) values so update and non-update iterations see one system
 #pragma unroll

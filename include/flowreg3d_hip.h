@@ -52,7 +52,9 @@ typedef struct fr3d_params {
                                           2: fp64 storage and arithmetic in the solver (2x the
                                              bytes; for configurations where the reference's own
                                              iteration is ill-conditioned);
-                                          FR3D_SOLVER_AUTO (-1): 1 for one channel, 2 for several
+                                          FR3D_SOLVER_AUTO (-1): the cheapest mode measured to stay within
+                                             1e-4 voxels of the reference CPU path -- 1 for one channel up to
+                                             2^25 voxels, 2 for larger volumes and for several channels
                                              (what the Python mirror passes by default) */
     int reserved[7];
 } fr3d_params;

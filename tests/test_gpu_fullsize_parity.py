@@ -6,9 +6,11 @@ deterministic synthetic inputs of flowreg3d_amd.synthetic.fullsize_case(); a str
 (every 8th voxel per axis) and one central 32^3 block of its flow field are committed as
 tests/golden/fullsize_<cfg>.npz together with the SHA-256 of the inputs
 (tools/gen_fullsize_golden.py).  Here the same inputs are regenerated, their checksum verified,
-the HIP path runs in its DEFAULT solver mode (the mode bench.py times: fp32 solver storage with fp64
-update arithmetic for one channel, fp64 storage for several) at the full 100 iterations, and the
-flow is compared on the sample.
+the HIP path runs in its DEFAULT solver mode (FR3D_SOLVER_AUTO, what the Python mirror, the executor and
+bench.py pass: fp32 solver storage with fp64 update arithmetic for one channel up to 2^25 voxels -- config 2;
+fp64 storage for larger volumes -- config 3 -- and for several channels -- config 5) at the full 100
+iterations, and the flow is compared on the sample.  The fp32-storage mode at 512^3, which bench.py also
+times, is measured by its own test below: 1.5e-4, above the bound, which is why AUTO leaves it at that size.
 
 Tolerance: mean end-point error < 1e-4 voxels (BASELINE.json north_star), on the lattice and on the
 block; the maxima are reported in the assertion message and bounded loosely (single voxels next to
@@ -73,3 +75,20 @@ def test_fullsize_flow_matches_oracle_sample(hip, case):
     gpu_gt, _ = _epe(flow[::st, ::st, ::st][1:-1, 1:-1, 1:-1], g["gt_lattice"][1:-1, 1:-1, 1:-1])
     cpu_gt, _ = _epe(g["lattice"][1:-1, 1:-1, 1:-1], g["gt_lattice"][1:-1, 1:-1, 1:-1])
     assert abs(gpu_gt - cpu_gt) < 1e-3 * max(1.0, cpu_gt), (gpu_gt, cpu_gt)
+
+
+def test_cfg3_fp32_storage_is_measured_and_stated(hip):
+    """512^3 with fp32 solver storage (solver_fp64=1, the mode the 76 B / update roofline figure is defined on and
+    bench.py's `cfg3_fp32_storage` leg times): mean EPE against the CPU sample 1.5e-4 -- ABOVE the 1e-4 bound, stated
+    as such in DESIGN.md and in the bench line; increments, frozen system and factors each cost about 1e-4 at this size
+    when held in fp32 (profiles/r02/numerics_512_rounding_groups.md).  The test pins the measured level (< 2e-4)."""
+    import flowreg3d_amd as fr
+    from flowreg3d_amd.synthetic import fullsize_case
+    g, meta = _load("cfg3")
+    fixed, moving, gt, kw = fullsize_case("cfg3")
+    assert _digest(fixed, moving) == meta["inputs_sha256"]
+    flow = fr.get_displacement(fixed, moving, solver_fp64=1, **kw)
+    st = meta["stride"]
+    lat_mean, lat_max = _epe(flow[::st, ::st, ::st], g["lattice"])
+    print(f"cfg3, fp32 solver storage: EPE vs oracle lattice mean {lat_mean:.3e} max {lat_max:.3e}")
+    assert 5e-5 < lat_mean < 2e-4, lat_mean

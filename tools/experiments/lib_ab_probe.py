@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two builds of the engine (FR3D_LIB selects the shared library; one process per build, alternated):
-SOR time per volume and the whole step.  usage (GPU box): python tools/experiments/lib_ab_probe.py EDGE BATCH LIB_A LIB_B [reps]"""
+SOR time per volume and the whole step; LIB may carry one environment setting as path.so@VAR=value.
+usage (GPU box): python tools/experiments/lib_ab_probe.py EDGE BATCH LIB_A LIB_B [reps]"""
 import json
 import os
 import subprocess
@@ -52,11 +53,15 @@ def main():
     n, nb, la, lb = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
     reps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     for rep in range(reps):
-        for tag, lib in (("A", la), ("B", lb)):
+        for tag, spec in (("A", la), ("B", lb)):
+            lib, _, setting = spec.partition("@")  # "path/to/lib.so@VAR=value" sets VAR for that side
             env = dict(os.environ, FR3D_LIB=os.path.abspath(lib))
+            if setting:
+                k, _, v = setting.partition("=")
+                env[k] = v
             r = subprocess.run([sys.executable, "-c", CHILD, n, nb], env=env, capture_output=True, text=True, timeout=600)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            print(json.dumps({"edge": int(n), "batch": int(nb), "lib": tag + ":" + os.path.basename(lib), "rep": rep,
+            print(json.dumps({"edge": int(n), "batch": int(nb), "lib": tag + ":" + os.path.basename(spec), "rep": rep,
                               **(json.loads(line[-1]) if line else {"error": r.stderr[-300:]})}), flush=True)
 
 
