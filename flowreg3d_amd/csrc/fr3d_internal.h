@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
@@ -55,11 +56,30 @@ struct Skew {
     int Yp;           // row pitch (Y rounded up to 64 elements)
     int S;            // number of hyperplanes
     long long plane;  // Z*Yp
-    long long total;  // S*plane
+    long long total;  // elements of one array: S*plane, or the packed size when pb/cp are set
+    // COMPACT variant (the a_smooth == 1 sweep and its operands): the rows of a hyperplane are packed back
+    // to back, each padded to a multiple of 64 elements (256-B aligned starts, no unused tail of up to
+    // Yp - len elements per row): 1.1-1.3x the voxel count instead of 3x.  Row (s,k) starts at
+    //     pb[s + 1] - cp[s - k + 1]
+    // with cp[n] = padded lengths of the rows r' = i+j < n summed (a row's length depends on r' only) and
+    // pb[s + 1] = start of plane s + cp[s - klo(s) + 1]; both tables are tiny (S + 2 and X + Y + 2 entries) and
+    // stay in the scalar / vector caches.  nullptr: the pitched layout above.
+    const long long *pb;
+    const int *cp;
 };
 
 __host__ __device__ static inline int sk_jm(int X, int r) { return r > X - 1 ? r - (X - 1) : 0; }
+// storage index of lane 0 of row (s,k); valid rows only (0 <= k < Z, 0 <= s - k <= X + Y - 2)
+__host__ __device__ static inline long long sk_row(const Skew &sk, int s, int k)
+{
+    return sk.pb ? sk.pb[s + 1] - (long long)sk.cp[s - k + 1] : (long long)s * sk.plane + (long long)k * sk.Yp;
+}
 // storage index of interior voxel (z,y,x)
+__host__ __device__ static inline long long sk_index(const Skew &sk, int z, int y, int x)
+{
+    return sk_row(sk, x + y + z, z) + (y - sk_jm(sk.X, x + y));
+}
+// pitched layout only (kernels that receive the geometry as scalars)
 __host__ __device__ static inline long long sk_index(int X, int Yp, long long plane, int z, int y, int x)
 {
     return (long long)(x + y + z) * plane + (long long)z * Yp + (y - sk_jm(X, x + y));
@@ -73,7 +93,31 @@ static inline Skew make_skew(int Z, int Y, int X)
     k.S = X + Y + Z - 2;
     k.plane = (long long)Z * k.Yp;
     k.total = (long long)k.S * k.plane;
+    k.pb = nullptr;
+    k.cp = nullptr;
     return k;
+}
+
+// Host tables of the compact variant: pb (S + 2 entries), cp (X + Y + 2 entries); returns the packed size.
+static inline long long make_compact_tables(int Z, int Y, int X, std::vector<long long> &pb, std::vector<int> &cp)
+{
+    const int S = X + Y + Z - 2, R = X + Y - 1;  // rows have r = i + j in [0, R)
+    cp.assign((size_t)X + Y + 2, 0);
+    for (int n = 1; n < X + Y + 2; n++) {
+        const int r = n - 1;
+        int len = 0;
+        if (r < R) len = std::min(Y - 1, r) - sk_jm(X, r) + 1;
+        cp[n] = cp[n - 1] + ((len + 63) / 64) * 64;
+    }
+    pb.assign((size_t)S + 2, 0);
+    long long start = 0;
+    for (int s = 0; s < S; s++) {
+        const int klo = std::max(0, s - (R - 1)), khi = std::min(Z - 1, s);
+        pb[s + 1] = start + cp[s - klo + 1];
+        start += (long long)cp[s - klo + 1] - (long long)cp[s - khi];
+    }
+    pb[S + 1] = start;
+    return start;
 }
 
 // Solver operands of the a_smooth == 1 sweep (k_sor.hip).  S is the storage type of everything the sweep
@@ -180,7 +224,8 @@ void launch_skew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD 
 template <typename TS, typename TD>
 void launch_unskew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst,
                           long long dst_stride, int narr, const Skew &sk);
-// nrec (3 or 12) natural planar arrays, src_stride elements apart -> one skewed array of nrec-value records
+// nrec (1, 3 or 12) natural planar arrays, src_stride elements apart -> one skewed array of nrec-value records
+// (pitched or compact layout, whatever `sk` describes)
 template <typename TS, typename TD>
 void launch_skew_pack(hipStream_t st, const TS *src, long long src_stride, TD *dst, int nrec, const Skew &sk);
 // skewed records of nrec (3) values -> nrec natural planar arrays, dst_stride elements apart

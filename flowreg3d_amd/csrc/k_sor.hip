@@ -37,8 +37,7 @@ __global__ void __launch_bounds__(SOR_BX * SOR_BY_MAX)
 k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent,
            const int *__restrict__ lut)
 {
-    const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X, Yp = a.sk.Yp;
-    const long long plane = a.sk.plane;
+    const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X;
     // blockIdx.x enumerates the tiles of all in-flight iterations (schedule built on the host)
     const int vol = blockIdx.y;
     const int b = blockIdx.x;
@@ -51,7 +50,8 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
     const int local = b - en.pre;
     const int t = t_lo + lo;
     const int s = tau - 2 * t;
-    const int k = (en.kb0 + local / en.njb) * (int)blockDim.y + threadIdx.y;
+    // a wave is one row (blockDim.x == 64): its row number is wave-uniform, which keeps the row starts in SGPRs
+    const int k = (en.kb0 + local / en.njb) * (int)blockDim.y + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
     if (k >= Z) return;
     const int r = s - k;                       // i + j of this row
     const int jm0 = sk_jm(X, r);               // first valid j of the row (left-aligned storage)
@@ -60,19 +60,31 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
     const int i = r - j;
     if (r < 0 || j >= Y || i < 0) return;      // i < X holds by construction of jm0
 
-    // voxel (record) indices of the voxel and of its six neighbours inside one volume's arrays.
+    // voxel (record) indices of the voxel and of its six neighbours inside one volume's arrays: row start
+    // (wave-uniform) + lane.  Compact layout: rows of the planes s-1, s, s+1 start at pb[.] - cp[.] (see Skew);
+    // the rows k-1 and k+1 of the neighbouring planes have the same i+j as this row, hence the same cp entry.
     // A ghost neighbour holds the voxel's own old value (set_boundary_3d): a missing neighbour
     // re-reads c0 (not yet overwritten), so all seven increment records are loaded unconditionally and
     // leave together instead of hiding behind exec-mask branches that wait for du0.
-    const long long c0 = (long long)s * plane + (long long)k * Yp + jj;
+    long long b0, bm, bzm, bp, bzp;  // row starts: own, (s-1,k), (s-1,k-1), (s+1,k), (s+1,k+1)
+    if (a.sk.pb) {
+        const long long pm = a.sk.pb[s], p0 = a.sk.pb[s + 1], pp = a.sk.pb[s + 2];
+        const long long cm = a.sk.cp[r], c_ = a.sk.cp[r + 1], cpn = a.sk.cp[r + 2];
+        b0 = p0 - c_; bm = pm - cm; bzm = pm - c_; bp = pp - cpn; bzp = pp - c_;
+    } else {
+        const long long plane = a.sk.plane, Yp = a.sk.Yp;
+        b0 = (long long)s * plane + (long long)k * Yp;
+        bm = b0 - plane; bzm = bm - Yp; bp = b0 + plane; bzp = bp + Yp;
+    }
+    const long long c0 = b0 + jj;
     const int d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
     S *const D = a.d + vol * a.vsD;
-    const long long xm = i > 0 ? c0 - plane + d1 : c0;
-    const long long xp = i < X - 1 ? c0 + plane + d2 : c0;
-    const long long ym = j > 0 ? c0 - plane + d1 - 1 : c0;
-    const long long yp = j < Y - 1 ? c0 + plane + d2 + 1 : c0;
-    const long long zm = k > 0 ? c0 - plane - Yp : c0;
-    const long long zp = k < Z - 1 ? c0 + plane + Yp : c0;
+    const long long xm = i > 0 ? bm + jj + d1 : c0;
+    const long long xp = i < X - 1 ? bp + jj + d2 : c0;
+    const long long ym = j > 0 ? bm + jj + d1 - 1 : c0;
+    const long long yp = j < Y - 1 ? bp + jj + d2 + 1 : c0;
+    const long long zm = k > 0 ? bzm + jj : c0;
+    const long long zp = k < Z - 1 ? bzp + jj : c0;
     const Rec<S, 3> q0 = ldrec<S, 3>(D, c0);
     const Rec<S, 3> qxm = ldrec<S, 3>(D, xm), qxp = ldrec<S, 3>(D, xp);
     const Rec<S, 3> qym = ldrec<S, 3>(D, ym), qyp = ldrec<S, 3>(D, yp);
@@ -359,9 +371,9 @@ template void launch_unskew_copy_n<double, float>(hipStream_t, const double *, l
 #define PKX 32
 template <typename TS, typename TD, int NREC, int TY>
 __global__ void __launch_bounds__(256)
-k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ dst, int Z, int Y, int X, int Yp,
-            long long plane, int to_skew)
+k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ dst, const Skew sk, int to_skew)
 {
+    const int Y = sk.Y, X = sk.X;
     // pitch 34: element (ly, d - ly) of a diagonal sits at 33*ly + d -> consecutive banks for consecutive ly
     __shared__ TD tile[NREC][TY][PKX + 2];
     const int txn = (X + PKX - 1) / PKX;
@@ -387,7 +399,7 @@ k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ d
             const int ly = lane, lx = d - lane;
             const int y = y0 + ly, x = x0 + lx;
             if (ly < TY && lx >= 0 && lx < PKX && y < Y && x < X) {
-                TD *o = dst + (size_t)sk_index(X, Yp, plane, z, y, x) * NREC;
+                TD *o = dst + (size_t)sk_index(sk, z, y, x) * NREC;
 #pragma unroll
                 for (int a = 0; a < NREC; a++) o[a] = tile[a][ly][lx];
             }
@@ -397,7 +409,7 @@ k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ d
             const int ly = lane, lx = d - lane;
             const int y = y0 + ly, x = x0 + lx;
             if (ly < TY && lx >= 0 && lx < PKX && y < Y && x < X) {
-                const TS *o = src + (size_t)sk_index(X, Yp, plane, z, y, x) * NREC;
+                const TS *o = src + (size_t)sk_index(sk, z, y, x) * NREC;
 #pragma unroll
                 for (int a = 0; a < NREC; a++) tile[a][ly][lx] = (TD)o[a];
             }
@@ -420,17 +432,17 @@ static void launch_pack_t(hipStream_t st, const TS *src, long long stride, TD *d
     constexpr int TY = (sizeof(TD) * NREC > 48) ? 16 : 32;
     FR3D_CHECK(sk.Z <= 65535, "skew transposes: z axis longer than 65535");
     dim3 grid(cdiv(sk.X, PKX) * cdiv(sk.Y, TY), sk.Z);
-    hipLaunchKernelGGL((k_skew_pack<TS, TD, NREC, TY>), grid, dim3(256), 0, st, src, stride, dst, sk.Z, sk.Y, sk.X, sk.Yp,
-                       sk.plane, to_skew);
+    hipLaunchKernelGGL((k_skew_pack<TS, TD, NREC, TY>), grid, dim3(256), 0, st, src, stride, dst, sk, to_skew);
     FR3D_LAUNCH_CHECK();
 }
 
 template <typename TS, typename TD>
 void launch_skew_pack(hipStream_t st, const TS *src, long long src_stride, TD *dst, int nrec, const Skew &sk)
 {
-    if (nrec == 3) launch_pack_t<TS, TD, 3>(st, src, src_stride, dst, sk, 1);
+    if (nrec == 1) launch_pack_t<TS, TD, 1>(st, src, src_stride, dst, sk, 1);
+    else if (nrec == 3) launch_pack_t<TS, TD, 3>(st, src, src_stride, dst, sk, 1);
     else if (nrec == 12) launch_pack_t<TS, TD, 12>(st, src, src_stride, dst, sk, 1);
-    else throw Error("internal: records of 3 or 12 values");
+    else throw Error("internal: records of 1, 3 or 12 values");
 }
 template <typename TS, typename TD>
 void launch_unskew_unpack(hipStream_t st, const TS *src, TD *dst, long long dst_stride, int nrec, const Skew &sk)
@@ -440,6 +452,7 @@ void launch_unskew_unpack(hipStream_t st, const TS *src, TD *dst, long long dst_
 }
 template void launch_skew_pack<float, float>(hipStream_t, const float *, long long, float *, int, const Skew &);
 template void launch_skew_pack<double, double>(hipStream_t, const double *, long long, double *, int, const Skew &);
+template void launch_skew_pack<float, double>(hipStream_t, const float *, long long, double *, int, const Skew &);
 template void launch_unskew_unpack<float, float>(hipStream_t, const float *, float *, long long, int, const Skew &);
 template void launch_unskew_unpack<double, float>(hipStream_t, const double *, float *, long long, int, const Skew &);
 
