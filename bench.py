@@ -207,8 +207,9 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
                                      batch.ptr + i * nv * 4))
     gflow.free()
 
-    # default lock-step batch: 8; at 512^3 4 slabs of solver operands (43 GB each, fp32 storage) or 2 (86 GB, fp64)
-    batch_vols = max(1, min(K, batch_arg if batch_arg > 0 else ((2 if mode == 2 else 4) if workload == "cfg3" else 8)))
+    # default lock-step batch: 8 at 256^3, 4 at 512^3 (the compact solver slabs of a 512^3 volume take 16 GB with
+    # fp32 storage, 33 GB with fp64 storage; batch 8 fits too and runs at the same rate per volume)
+    batch_vols = max(1, min(K, batch_arg if batch_arg > 0 else (4 if workload == "cfg3" else 8)))
     lib.fr3d_set_batch(batch_vols)  # warm-up and timed run use the same lock-step batch / workspace
 
     def run(first, count, prof):
@@ -267,7 +268,7 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
             pmc = pj.get(workload)
             if pmc and mode < 2:
                 traffic = pmc["bytes_per_update"] * sor["units"] / max(sor["launches"], 1)
-                traffic_source = f"profiles/pmc_traffic.json ({pj.get('_taken_at', 'round 1, commit 0249743')}): " \
+                traffic_source = f"profiles/pmc_traffic.json ({pj.get('_taken_at', 'unknown round')}): " \
                                  f"{pmc['bytes_per_update']:.1f} B per voxel update x this run's updates per launch"
         except (OSError, ValueError, KeyError):
             traffic = None
@@ -329,8 +330,7 @@ def main():
                          "voxels, fp64 storage beyond -- the cheapest mode measured to stay within 1e-4 voxels of the CPU "
                          "path); 0 fp32 storage+update, 1 fp32 storage with fp64 update arithmetic, 2 fp64 storage")
     ap.add_argument("--batch", type=int, default=0,
-                    help="volumes solved in lock step per GPU (shared launches); 0 = 8, or 4 at 512^3 "
-                         "where 8 slabs of solver operands (43 GB each) would not fit in 288 GB")
+                    help="volumes solved in lock step per GPU (shared launches); 0 = 8 at 256^3, 4 at 512^3")
     ap.add_argument("--condition", type=float, default=30.0,
                     help="seconds of untimed warm-up work before the timed steps (0 = only the W warm-up steps)")
     args = ap.parse_args()
@@ -368,7 +368,7 @@ def main():
     lib = _lib.init(dev_index)
     K, W = args.steps, args.warmup
     m = measure(lib, _lib, args.workload, K, W, args.batch, args.condition, args.solver_fp64, rank, world, dist,
-                dev_index, fast_inputs=False)
+                dev_index, fast_inputs=args.workload == "cfg3")
 
     if rank == 0:
         elapsed = m["elapsed"]

@@ -28,10 +28,16 @@ def counter(path, kernel, name):
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     out = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) of "
-                    "`bench.py --workload W --steps 1 --warmup 0 --batch 1`, kernel k_sor_step; FETCH_SIZE "
+                    "`bench.py --workload W --steps 1 --warmup 0 --batch 1 --solver-fp64 1 --no-extras` (fp32 solver storage), kernel k_sor_step; FETCH_SIZE "
                     "doubled per MI355X_MICROARCH.md (calibrated in the same pass on k_axpy, which reports "
                     "exactly 1/2 of a known 4-B-per-lane coalesced stream); KiB units; made by "
                     "tools/make_pmc_traffic.py " + tag}
+    import subprocess
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = "?"
+    out["_taken_at"] = f"round {tag.lstrip('r0') or '?'}, kernel as of commit {head or '?'} (record layout, compact rows)"
     for wl in ("cfg2", "cfg3"):
         Z, Y, X, levels, _ = bench.WORKLOADS[wl]
         kw = bench.solver_kwargs(levels)
@@ -52,7 +58,7 @@ def main():
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
-    print(json.dumps({k: v["bytes_per_update"] for k, v in out.items() if k != "_note"}))
+    print(json.dumps({k: v["bytes_per_update"] for k, v in out.items() if not k.startswith("_")}))
 
 
 if __name__ == "__main__":
