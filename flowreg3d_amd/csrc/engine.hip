@@ -532,16 +532,22 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                     // only the square-root factors are needed: the solver rebuilds the tensor from
                     // them on psi-update iterations and keeps its own frozen 3x3 system in between
                     float *Jo[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-                    launch_motion_tensor<S>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
-                                            hx, Jo, nat, (long long)nl, nullptr);
                     S *Adst = Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns;
-                    if (fast) launch_skew_pack<S, S>(e.st, nat, (long long)nl, Adst, 12, sk);
-                    else launch_skew_copy_n<S, S>(e.st, nat, (long long)nl, Adst, (long long)ns, 12, sk);
+                    if (fast) {  // factors straight into the record layout
+                        launch_motion_tensor_rec<S>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, hz, hy, hx, Adst, sk);
+                    } else {
+                        launch_motion_tensor<S>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
+                                                hx, Jo, nat, (long long)nl, nullptr);
+                        launch_skew_copy_n<S, S>(e.st, nat, (long long)nl, Adst, (long long)ns, 12, sk);
+                    }
                 }
-                S *Ln = nat + 12 * nl;
-                launch_laplace<S>(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Ln, Ln + nl, Ln + 2 * nl, true);
-                if (fast) launch_skew_pack<S, S>(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, 3, sk);
-                else launch_skew_copy_n<S, S>(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, (long long)ns, 3, sk);
+                if (fast) {
+                    launch_laplace_rec<S>(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Lbuf + (size_t)b * a.vsL);
+                } else {
+                    S *Ln = nat + 12 * nl;
+                    launch_laplace<S>(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Ln, Ln + nl, Ln + 2 * nl, true);
+                    launch_skew_copy_n<S, S>(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, (long long)ns, 3, sk);
+                }
             }
         }
         a.iterations = p.iterations;

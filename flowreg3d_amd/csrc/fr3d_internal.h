@@ -216,6 +216,12 @@ void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int 
                           double hz, double hy, double hx, float *const Jout[10], TA *A,
                           long long a_stride, const Skew *sk);
 
+// K3 straight into the solver's record layout: dst = 12 factor values per voxel in the (compact or pitched)
+// skewed voxel order of `sk`
+template <typename TA>
+void launch_motion_tensor_rec(hipStream_t st, const float *f1, const float *f2, double hz, double hy, double hx,
+                              TA *dst, const Skew &sk);
+
 // K4-K7 SOR
 // narr arrays, src_stride / dst_stride elements apart; element types may differ (converted)
 template <typename TS, typename TD>
@@ -235,6 +241,10 @@ void launch_unskew_unpack(hipStream_t st, const TS *src, TD *dst, long long dst_
 template <typename TL>
 void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
                     double ax, double ay, double az, TL *Lu, TL *Lv, TL *Lw, bool natural = false);
+// the same three terms as one record per voxel in the skewed order of `sk`
+template <typename TL>
+void launch_laplace_rec(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk, double ax,
+                        double ay, double az, TL *dst);
 // Launch schedule of one level geometry: for every launch tau and every in-flight iteration t the
 // bounding box (in tile units) of the valid part of hyperplane s = tau - 2t, so that only tiles that
 // can hold voxels are dispatched (an all-covering grid spends ~8 us per launch on empty workgroups).

@@ -489,6 +489,66 @@ k_laplace(const float *__restrict__ u, const float *__restrict__ v, const float 
     }
 }
 
+// The same three terms written as one record per voxel in the skewed voxel order of `sk` (compact or pitched),
+// through an LDS tile like k_skew_pack / k_motion_tensor_rec.
+template <typename TL>
+__global__ void __launch_bounds__(256)
+k_laplace_rec(const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w, const Skew sk,
+              double ax, double ay, double az, TL *__restrict__ dst)
+{
+    __shared__ TL tile[3][32][PKX + 2];
+    const int Z = sk.Z, Y = sk.Y, X = sk.X;
+    const int txn = (X + PKX - 1) / PKX;
+    const int x0 = (blockIdx.x % txn) * PKX, y0 = (blockIdx.x / txn) * 32;
+    const int z = blockIdx.y;
+    const int lane = threadIdx.x % PKX, grp = threadIdx.x / PKX;
+    const long long sx = 1, sy = X, sz = (long long)Y * X;
+    const float *f[3] = {u, v, w};
+    for (int ly = grp; ly < 32; ly += 8) {
+        const int y = y0 + ly, x = x0 + lane;
+        if (y < Y && x < X) {
+            const long long t = ((long long)z * Y + y) * X + x;
+            const long long xm = x > 0 ? -sx : 0, xp = x < X - 1 ? sx : 0;
+            const long long ym = y > 0 ? -sy : 0, yp = y < Y - 1 ? sy : 0;
+            const long long zm = z > 0 ? -sz : 0, zp = z < Z - 1 ? sz : 0;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float *q = f[d] + t;
+                double c = (double)q[0];
+                double acc = ax * ((double)q[xp] + (double)q[xm] - 2.0 * c);
+                acc += ay * ((double)q[yp] + (double)q[ym] - 2.0 * c);
+                acc += az * ((double)q[zp] + (double)q[zm] - 2.0 * c);
+                tile[d][ly][lane] = (TL)acc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int d = grp; d < 32 + PKX - 1; d += 8) {
+        const int ly = lane, lx = d - lane;
+        const int y = y0 + ly, x = x0 + lx;
+        if (lx >= 0 && lx < PKX && y < Y && x < X) {
+            TL *o = dst + (size_t)sk_index(sk, z, y, x) * 3;
+            o[0] = tile[0][ly][lx];
+            o[1] = tile[1][ly][lx];
+            o[2] = tile[2][ly][lx];
+        }
+    }
+}
+
+template <typename TL>
+void launch_laplace_rec(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk, double ax,
+                        double ay, double az, TL *dst)
+{
+    FR3D_CHECK(sk.Z <= 65535, "laplace: z axis longer than 65535");
+    dim3 grid(cdiv(sk.X, PKX) * cdiv(sk.Y, 32), sk.Z);
+    hipLaunchKernelGGL(k_laplace_rec<TL>, grid, dim3(256), 0, st, u, v, w, sk, ax, ay, az, dst);
+    FR3D_LAUNCH_CHECK();
+}
+template void launch_laplace_rec<float>(hipStream_t, const float *, const float *, const float *, const Skew &, double,
+                                        double, double, float *);
+template void launch_laplace_rec<double>(hipStream_t, const float *, const float *, const float *, const Skew &, double,
+                                         double, double, double *);
+
 template <typename TL>
 void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
                     double ax, double ay, double az, TL *Lu, TL *Lv, TL *Lw, bool natural)

@@ -16,7 +16,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libfr3d_oracle.so")
+# FR3D_ORACLE_SO: an alternative build of the same source (e.g. with FMA contraction) for reproducibility studies
+_SO = os.environ.get("FR3D_ORACLE_SO") or os.path.join(_HERE, "_build", "libfr3d_oracle.so")
 _lib = None
 
 _dp = C.POINTER(C.c_double)
