@@ -314,12 +314,15 @@ void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float 
     if (mode == 1) {
         long long total = (long long)Z * Y * X;
         hipLaunchKernelGGL(k_median5, dim3(cdiv(total, 256)), dim3(256), 0, st, in, Z, Y, X, out);
+        FR3D_LAUNCH_CHECK();
     } else if (mode == 2 || Z > 65535 || cdiv(Y, MB_Y) > 65535) {
         long long total = (long long)Z * Y * ((X + 1) / 2);
         hipLaunchKernelGGL(k_median5_x2, dim3(cdiv(total, 256)), dim3(256), 0, st, in, Z, Y, X, out);
+        FR3D_LAUNCH_CHECK();
     } else {
         dim3 grid(cdiv(X, 2 * MB_XP), cdiv(Y, MB_Y), Z);
         hipLaunchKernelGGL(k_median5_lds, grid, dim3(256), 0, st, in, Z, Y, X, out);
+        FR3D_LAUNCH_CHECK();
     }
 }
 

@@ -23,6 +23,7 @@ __global__ void __launch_bounds__(256) k_read8(const float *__restrict__ x, long
 void launch_read8(hipStream_t st, const float *x, long long n, float *sink)
 {
     if (n > 0) hipLaunchKernelGGL(k_read8, dim3(cdiv(n, 256)), dim3(256), 0, st, x, n, sink);
+    FR3D_LAUNCH_CHECK();
 }
 
 __global__ void __launch_bounds__(256) k_fill(float *__restrict__ y, float v, long long n)
@@ -97,18 +98,22 @@ void launch_mean_store(hipStream_t st, const double *acc, long long n, int C, in
 void launch_axpy(hipStream_t st, float *y, const float *x, long long n)
 {
     if (n > 0) hipLaunchKernelGGL(k_axpy, dim3(cdiv(n, 256)), dim3(256), 0, st, y, x, n);
+    FR3D_LAUNCH_CHECK();
 }
 void launch_fill(hipStream_t st, float *y, float v, long long n)
 {
     if (n > 0) hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, y, v, n);
+    FR3D_LAUNCH_CHECK();
 }
 void launch_pack(hipStream_t st, const float *planar, int C, long long n, float *inter)
 {
     if (n > 0) hipLaunchKernelGGL(k_pack, dim3(cdiv(n * C, 256)), dim3(256), 0, st, planar, C, n, inter);
+    FR3D_LAUNCH_CHECK();
 }
 void launch_unpack(hipStream_t st, const float *inter, int C, long long n, float *planar)
 {
     if (n > 0) hipLaunchKernelGGL(k_unpack, dim3(cdiv(n * C, 256)), dim3(256), 0, st, inter, C, n, planar);
+    FR3D_LAUNCH_CHECK();
 }
 
 }  // namespace fr3d
@@ -165,6 +170,7 @@ k_flow_stats(const float *__restrict__ flow, int Z, int Y, int X, double *__rest
 void launch_flow_stats(hipStream_t st, const float *flow, int Z, int Y, int X, int nblocks, double *partial)
 {
     hipLaunchKernelGGL(k_flow_stats, dim3(nblocks), dim3(256), 0, st, flow, Z, Y, X, partial);
+    FR3D_LAUNCH_CHECK();
 }
 
 }  // namespace fr3d

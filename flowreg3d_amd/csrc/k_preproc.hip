@@ -63,6 +63,7 @@ void launch_gauss_pass(hipStream_t st, const TIN *in, int cs, int co, double nmi
     if (total == 0) return;
     hipLaunchKernelGGL(k_gauss_pass<TIN>, dim3(cdiv(total, 256)), dim3(256), 0, st, in, cs, co, nmin, nden, T, Z, Y,
                        X, axis, w, radius, out);
+    FR3D_LAUNCH_CHECK();
 }
 template void launch_gauss_pass<float>(hipStream_t, const float *, int, int, double, double, int, int, int, int, int, const double *, int, double *);
 template void launch_gauss_pass<double>(hipStream_t, const double *, int, int, double, double, int, int, int, int, int, const double *, int, double *);
@@ -83,6 +84,7 @@ template <typename TOUT>
 void launch_store_channel(hipStream_t st, const double *in, long long n, int C, int c, TOUT *out)
 {
     if (n > 0) hipLaunchKernelGGL(k_store_channel<TOUT>, dim3(cdiv(n, 256)), dim3(256), 0, st, in, n, C, c, out);
+    FR3D_LAUNCH_CHECK();
 }
 template void launch_store_channel<float>(hipStream_t, const double *, long long, int, int, float *);
 template void launch_store_channel<double>(hipStream_t, const double *, long long, int, int, double *);

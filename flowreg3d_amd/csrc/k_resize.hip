@@ -149,6 +149,7 @@ void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0
         FR3D_TAP_SWITCH(P, FR3D_RM)
 #undef FR3D_RM
     }
+    FR3D_LAUNCH_CHECK();
 }
 
 }  // namespace fr3d

@@ -9,13 +9,14 @@
 // `iterations` hyperplanes at once -- and reproduces the sequential sweep exactly (same
 // neighbour states), with S + 2(iterations-1) launches per level instead of iterations*S.
 //
-// Data sits in the skewed layout of fr3d_internal.h, so a wave reads/writes contiguous j-runs
-// and the six neighbours are row-uniform offsets.  The algorithmic traffic of the reference's
-// update is 9C tensor entries + C (w*psi) + 3 Laplacian terms + 3 increments read, 3 written:
-// 4*(10C+9) bytes (76 B for C = 1) -- the figure bench.py prices the kernel against.  The kernel
-// itself streams less: between psi updates the per-voxel 3x3 system (6+3 floats, channels summed)
-// is frozen, so ordinary iterations read 9 + 3 floats and write 3; psi-update iterations (every
-// update_lag-th) read the 12C square-root factors + C weights + 3 L + 3 d and write 9 + 3.
+// Data sits in the skewed layout of fr3d_internal.h (compact rows, one record per voxel and operand group), so a
+// wave reads/writes contiguous j-runs and the six neighbours are row-uniform offsets.  The algorithmic traffic of
+// the reference's update is 9C tensor entries + C (w*psi) + 3 Laplacian terms + 3 increments read, 3 written:
+// (10C+9) values = 76 B for C = 1 with fp32 storage, 152 B with fp64 storage -- the figure bench.py prices the
+// kernel against.  The kernel itself streams less: between psi updates the per-voxel 3x3 system (6+3 values,
+// channels summed) is frozen, so ordinary iterations read a 9-value and seven 3-value records and write one
+// 3-value record; psi-update iterations (every update_lag-th) read the 12C square-root factors + C weights + 3 L
+// + the increments and write 9 + 3.
 //
 // Fusions: the Neumann ghost copy set_boundary_3d (:246-259) becomes "a missing neighbour is the
 // voxel's own old value"; the psi_data update (:356-377) is pointwise in the old increment, so it
@@ -340,9 +341,11 @@ static void launch_skew_tiled(hipStream_t st, const TS *src, long long src_strid
                               long long dst_stride, int narr, const Skew &sk, int to_skew)
 {
     if (narr <= 0) return;
+    FR3D_CHECK(sk.Z <= 65535 && narr <= 65535, "skew transposes: z axis longer than 65535");
     dim3 grid(cdiv(sk.X, SKT) * cdiv(sk.Y, SKT), sk.Z, narr);
     hipLaunchKernelGGL((k_skew_tiled<TS, TD>), grid, dim3(256), 0, st, src, src_stride, dst, dst_stride, sk.Z,
                        sk.Y, sk.X, sk.Yp, sk.plane, to_skew);
+    FR3D_LAUNCH_CHECK();
 }
 
 template <typename TS, typename TD>
@@ -556,6 +559,7 @@ void launch_laplace(hipStream_t st, const float *u, const float *v, const float 
     long long total = (long long)sk.Z * sk.Y * sk.X;
     hipLaunchKernelGGL(k_laplace<TL>, dim3(cdiv(total, 256)), dim3(256), 0, st, u, v, w, sk.Z, sk.Y,
                        sk.X, sk.Yp, natural ? 0LL : sk.plane, ax, ay, az, Lu, Lv, Lw);
+    FR3D_LAUNCH_CHECK();
 }
 
 template void launch_laplace<float>(hipStream_t, const float *, const float *, const float *, const Skew &, double,

@@ -187,6 +187,7 @@ void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int 
     hipLaunchKernelGGL(k_motion_tensor<TA>, dim3(cdiv(total, 256)), dim3(256), 0, st, a, b, hz, hy, hx,
                        J[0], J[1], J[2], J[3], J[4], J[5], J[6], J[7], J[8], J[9], A, a_stride, sk ? 1 : 0,
                        sk ? sk->Yp : 0, sk ? sk->plane : 0LL);
+    FR3D_LAUNCH_CHECK();
 }
 
 template void launch_motion_tensor<float>(hipStream_t, const float *, const float *, int, int, int, double, double,

@@ -41,6 +41,7 @@ void launch_pad_edge(hipStream_t st, const T *src, int cs, int co, int Z, int Y,
     long long total = (long long)(Z + 2 * npad) * (Y + 2 * npad) * (X + 2 * npad);
     hipLaunchKernelGGL(k_pad_edge<T>, dim3(cdiv(total, 256)), dim3(256), 0, st, src, cs, co, Z, Y,
                        X, npad, dst);
+    FR3D_LAUNCH_CHECK();
 }
 template void launch_pad_edge<float>(hipStream_t, const float *, int, int, int, int, int, int, double *);
 template void launch_pad_edge<double>(hipStream_t, const double *, int, int, int, int, int, int, double *);
@@ -256,6 +257,7 @@ void launch_prefilter3(hipStream_t st, double *c, int PZ, int PY, int PX)
                                (long long)PX, 0LL, PX, 1LL, zpow(PX));
         }
     }
+    FR3D_LAUNCH_CHECK();
 }
 
 // ---- 3. gather --------------------------------------------------------------------------------
