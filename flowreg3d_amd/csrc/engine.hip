@@ -187,7 +187,9 @@ struct DevBuf {
         if (bytes > cap) {
             if (p) FR3D_HIP(hipFree(p));
             p = nullptr; cap = 0;
-            size_t want = bytes + (bytes >> 4) + 256;
+            // a little headroom so that slightly larger requests reuse the buffer; capped, or the big slabs of a
+            // 1024^3 volume would waste tens of GB
+            size_t want = bytes + std::min<size_t>(bytes >> 4, (size_t)256 << 20) + 256;
             FR3D_HIP(hipMalloc(&p, want));
             cap = want;
         }
@@ -524,10 +526,10 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 warped = wbuf;
             }
             {
-                // tensor + factors + Laplacian terms are produced in the natural layout (coalesced
-                // stores) and moved to the skewed layout by the LDS-tiled transpose, 24 arrays a launch
+                // a_smooth == 1: factors and Laplacian terms go straight into the solver's records (LDS-tiled
+                // kernels); otherwise they are produced in the natural layout and moved by the tiled transpose
                 Span sp(e, FR3D_K_TENSOR, 4.0 * (2 + 12) * nl * C, C, (long long)nl * C);
-                S *nat = (S *)e.bufs["JAL_nat" + sn].ensure(nl * 15 * sizeof(S));
+                S *nat = fast ? nullptr : (S *)e.bufs["JAL_nat" + sn].ensure(nl * 15 * sizeof(S));
                 for (int c = 0; c < C; c++) {
                     // only the square-root factors are needed: the solver rebuilds the tensor from
                     // them on psi-update iterations and keeps its own frozen 3x3 system in between
@@ -625,7 +627,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
     const size_t nl = (size_t)pz * py * px;
     for (int b = 0; b < nb; b++) {
         float **u = &uvw[3 * b];
-        float *full = e.f32("flow_full", nfull * 3);
+        float *full = e.f32("d_nat", nfull * 3);  // the increments' scratch is free after the last level
         if (min_level > 0) {
             for (int d = 0; d < 3; d++) resize3d(e, u[d], 1, 0, pz, py, px, Z, Y, X, full + (size_t)d * nfull);
         } else {
@@ -693,10 +695,10 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
     const double nfin = (double)F.z * F.y * F.x;
     // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
     const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0) + nfin * 4.0 * 9.0;
-    // volume-independent scratch of the finest level: tensor/Laplacian staging (15), moving level and
-    // its warp (2C), fp64 spline coefficients on the padded grid (~2.5), increments and flow (9),
+    // volume-independent scratch of the finest level: tensor/Laplacian staging (15, a_smooth != 1 only), moving
+    // level and its warp (2C), fp64 spline coefficients on the padded grid (~2.5), increments and their median (6),
     // reference and weight pyramids (~4C)
-    const double scratch = nfin * 4.0 * (15.0 + 2.0 * C + 2.5 + 9.0 + 4.0 * C) * (g_fp64_storage ? 1.5 : 1.0);
+    const double scratch = nfin * 4.0 * ((g_fast_path ? 0.0 : 15.0) + 2.0 * C + 2.5 + 6.0 + 4.0 * C) * (g_fp64_storage && !g_fast_path ? 1.5 : 1.0);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         // what the solver slabs may occupy: the memory that is free now plus what the engine already
