@@ -602,7 +602,6 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         const bool med = std::min(lz, std::min(ly, lx)) > 5;
         for (int b = 0; b < nb; b++) {
             float *dn = e.f32("d_nat", nl * 3);
-            float *dm = e.f32("d_med", nl * 3);
             float **u = &uvw[3 * b];
             {
                 Span sp(e, FR3D_K_OTHER, 0, 0, 0);
@@ -611,6 +610,13 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 if (fast) launch_unskew_unpack<S, float>(e.st, dbuf + (size_t)b * a.vsD, dn, (long long)nl, 3, sk);
                 else launch_unskew_copy_n<S, float>(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
             }
+            if (med && median_can_accumulate(lz, ly, lx)) {
+                // one launch for du, dv, dw, the flow update u += median(du) fused (:517-529)
+                Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 1, (long long)nl * 3);
+                launch_median5_fields(e.st, dn, (long long)nl, 3, lz, ly, lx, u, true);
+                continue;
+            }
+            float *dm = med ? e.f32("d_med", nl * 3) : nullptr;
             if (med) {
                 Span sp(e, FR3D_K_MEDIAN, 8.0 * nl * 3, 3, (long long)nl * 3);
                 for (int d = 0; d < 3; d++) launch_median5(e.st, dn + (size_t)d * nl, lz, ly, lx, dm + (size_t)d * nl);

@@ -284,6 +284,10 @@ long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorS
 
 // K8 median (natural layout)
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);
+// nf <= 3 fields of one volume in one launch (field f at in + f*fstride): out[f] = median, or out[f] += median
+void launch_median5_fields(hipStream_t st, const float *in, long long fstride, int nf, int Z, int Y, int X,
+                           float *const *out, bool accumulate);
+bool median_can_accumulate(int Z, int Y, int X);
 
 // f-1 preprocessing (k_preproc.hip)
 template <typename TIN>

@@ -180,8 +180,8 @@ k_median5_x2(const float *__restrict__ in, int Z, int Y, int X, float *__restric
 
 // ---- slabs sorted once, exchanged through LDS ---------------------------------------------------
 // The 5x5 (z,y) slab at one x belongs to five windows.  A workgroup of 4 rows x 64 output pairs sorts
-// every slab of its 133 columns once (each thread its own two columns, five threads per row a halo
-// column too), publishes them in LDS as order-preserving integer keys, and each thread then builds
+// every slab of its 133 columns once (each thread its own two columns; the 20 halo columns of the four
+// rows in one extra pass of one wave), publishes them in LDS as order-preserving integer keys, and each thread then builds
 // its pair of medians from six sorted slabs: the four shared ones are MERGED (odd-even merge levels
 // only, 360 min/max pairs for the 26 candidate ranks instead of 932 for sorting them from scratch),
 // the two private ones are used as they are.  345 pairs per output.  Lists of 25 sit in 32-slot
@@ -252,26 +252,38 @@ k_median5_lds(const float *__restrict__ in, int Z, int Y, int X, float *__restri
         zo[q] = (long long)mirror(z + q - 2, Z) * Y * X;
         yo[q] = (long long)mirror(row_ok ? y + q - 2 : 0, Y) * X;
     }
-    auto sort_column = [&](int c) {
+    auto sort_column = [&](int c, int row, const long long (&yoff)[5]) {
         const int xm = mirror(X0 - 2 + c, X);
         int k[32];
 #pragma unroll
-        for (int n = 0; n < 25; n++) k[n] = f2key(in[zo[n / 5] + yo[n % 5] + xm]);
+        for (int n = 0; n < 25; n++) k[n] = f2key(in[zo[n / 5] + yoff[n % 5] + xm]);
 #pragma unroll
         for (int n = 25; n < 32; n++) k[n] = KEY_PAD;
         OESortI<32, 0, 32>::run(k);
         if (c & 1) {
 #pragma unroll
-            for (int n = 0; n < 25; n++) sO[n][ty][c >> 1] = k[n];
+            for (int n = 0; n < 25; n++) sO[n][row][c >> 1] = k[n];
         } else {
 #pragma unroll
-            for (int n = 0; n < 25; n++) sE[n][ty][c >> 1] = k[n];
+            for (int n = 0; n < 25; n++) sE[n][row][c >> 1] = k[n];
         }
     };
     if (row_ok) {
-        sort_column(2 * tx + 2);
-        sort_column(2 * tx + 3);
-        if (tx < 5) sort_column(tx < 2 ? tx : 2 * MB_XP + tx);  // halo columns 0,1 and 130,131,132
+        sort_column(2 * tx + 2, ty, yo);
+        sort_column(2 * tx + 3, ty, yo);
+    }
+    // the 4 x 5 halo columns (c = 0,1 and 130,131,132 of every row) cost one more sorting pass of ONE wave
+    // (a pass costs the same for 5 active lanes as for 64); which wave takes it rotates with the block so
+    // that the extra pass does not always land on the same SIMD
+    if (ty == ((blockIdx.x + blockIdx.y + blockIdx.z) & (MB_Y - 1)) && tx < 5 * MB_Y) {
+        const int hrow = tx / 5, h = tx - 5 * hrow;
+        const int hy = blockIdx.y * MB_Y + hrow;
+        if (hy < Y) {
+            long long hyo[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++) hyo[q] = (long long)mirror(hy + q - 2, Y) * X;
+            sort_column(h < 2 ? h : 2 * MB_XP + h, hrow, hyo);
+        }
     }
     __syncthreads();
     const int x0 = X0 + 2 * tx;
@@ -307,11 +319,163 @@ k_median5_lds(const float *__restrict__ in, int Z, int Y, int X, float *__restri
     }
 }
 
+// ---- flattened form: no tile quantisation, three fields per launch ------------------------------
+// k_median5_lds ties a wave to 128 consecutive outputs of one row: a 131-wide level fills 51 % of its
+// lanes, the five levels of a 256^3 pyramid 79 % on average.  Here the output pairs of a whole field are
+// numbered consecutively, P = (z*Y + y)*XP + xp, and a workgroup takes 256 consecutive pairs wherever
+// the rows break.  Slot L+1 of the exchange arrays holds the two sorted slabs of lane L (columns 2xp and
+// 2xp+1), slots 0 and 257 the two columns left of lane 0 and right of lane 255 (one extra pass of one
+// wave, four lanes).  The mirror boundary needs no slabs of its own: a mirrored column is a column of the
+// same row, so a lane at a row start or end only picks different slots.  Same network, same keys, same
+// result as k_median5_lds; `acc` adds the median to the destination (the flow update u += median(du),
+// core/optical_flow_3d.py:527-529) instead of storing it.
+#define MF_T 256
+#define MF_W (MF_T + 2)
+
+struct MedianDst {
+    float *p[3];
+    int acc;
+};
+
+__device__ __forceinline__ void median_offsets(int z, int y, int Z, int Y, int X, unsigned (&zo)[5], unsigned (&yo)[5])
+{
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        zo[q] = (unsigned)mirror(z + q - 2, Z) * (unsigned)Y * (unsigned)X;
+        yo[q] = (unsigned)mirror(y + q - 2, Y) * (unsigned)X;
+    }
+}
+
+__global__ void __launch_bounds__(MF_T) __attribute__((amdgpu_waves_per_eu(3, 4)))
+k_median5_flat(const float *__restrict__ in, long long fstride, int Z, int Y, int X, unsigned npairs, MedianDst dst)
+{
+    __shared__ int sK[2][25][MF_W];  // [column parity][rank][slot]
+    const int L = threadIdx.x;
+    const int XP = (X + 1) >> 1;
+    const float *__restrict__ src = in + (size_t)blockIdx.y * fstride;
+    auto sort_store = [&](const unsigned (&zo)[5], const unsigned (&yo)[5], int xm, int par, int slot) {
+        int k[32];
+#pragma unroll
+        for (int n = 0; n < 25; n++) k[n] = f2key(src[zo[n / 5] + yo[n % 5] + (unsigned)xm]);
+#pragma unroll
+        for (int n = 25; n < 32; n++) k[n] = KEY_PAD;
+        OESortI<32, 0, 32>::run(k);
+#pragma unroll
+        for (int n = 0; n < 25; n++) sK[par][n][slot] = k[n];
+    };
+    const unsigned P = blockIdx.x * (unsigned)MF_T + (unsigned)L;
+    const bool live = P < npairs;
+    int xp = 0, y = 0, z = 0;
+    if (live) {
+        xp = (int)(P % (unsigned)XP);
+        const unsigned r = P / (unsigned)XP;
+        y = (int)(r % (unsigned)Y);
+        z = (int)(r / (unsigned)Y);
+        unsigned zo[5], yo[5];
+        median_offsets(z, y, Z, Y, X, zo, yo);
+        sort_store(zo, yo, 2 * xp, 0, L + 1);
+        sort_store(zo, yo, mirror(2 * xp + 1, X), 1, L + 1);
+    }
+    // the columns outside the workgroup: x0-2, x0-1 of its first lane and x0+2, x0+3 of its last one.  One
+    // more sorting pass of one wave (a pass costs the same for 4 active lanes as for 64); the wave rotates
+    // with the workgroup so that the pass does not always land on the same SIMD.
+    if ((L >> 6) == (int)((blockIdx.x + blockIdx.y) & 3u) && (L & 63) < 4) {
+        const int h = L & 63;
+        const unsigned PH = blockIdx.x * (unsigned)MF_T + (h < 2 ? 0u : (unsigned)(MF_T - 1));
+        if (PH < npairs) {
+            const int hxp = (int)(PH % (unsigned)XP);
+            const unsigned r = PH / (unsigned)XP;
+            unsigned zo[5], yo[5];
+            median_offsets((int)(r / (unsigned)Y), (int)(r % (unsigned)Y), Z, Y, X, zo, yo);
+            const int col = 2 * hxp + (h == 0 ? -2 : h == 1 ? -1 : h == 2 ? 2 : 3);
+            sort_store(zo, yo, mirror(col, X), h & 1, h < 2 ? 0 : MF_W - 1);
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    // slots of the six columns x0-2 .. x0+3 (even columns in sK[0], odd ones in sK[1]); at a row start
+    // -2 -> 2 and -1 -> 1, at a row end X -> X-2 and X+1 -> X-3 (whole-sample symmetric)
+    const bool first = xp == 0, last = xp == XP - 1, oddX = (X & 1) != 0;
+    const int own = L + 1;
+    const int sl_m2 = first ? L + 2 : L;                   // x0-2 (even)
+    const int sl_m1 = first ? own : L;                     // x0-1 (odd)
+    const int sl_p2 = last ? (oddX ? L : own) : L + 2;     // x0+2 (even)
+    const int sl_p3 = last ? L : L + 2;                    // x0+3 (odd); not read for the last pair of an odd row
+    int s[128];
+#pragma unroll
+    for (int n = 0; n < 25; n++) {
+        s[n] = sK[1][n][sl_m1];
+        s[32 + n] = sK[0][n][own];
+        s[64 + n] = sK[1][n][own];
+        s[96 + n] = sK[0][n][sl_p2];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int n = 25; n < 32; n++) s[32 * b + n] = KEY_PAD;
+    OEMergeI<128, 0, 64, 1>::run(s);
+    OEMergeI<128, 64, 64, 1>::run(s);
+    OEMergeI<128, 0, 128, 1>::run(s);
+    float *__restrict__ out = dst.p[blockIdx.y];
+    const size_t o = ((size_t)z * Y + y) * X + 2 * xp;
+    {
+        int best = s[62];
+#pragma unroll
+        for (int i = 1; i <= 25; i++) best = min(best, max(s[36 + i], sK[0][25 - i][sl_m2]));  // private x0-2
+        const float m = key2f(best);
+        out[o] = dst.acc ? out[o] + m : m;
+    }
+    if (2 * xp + 1 < X) {
+        int best = s[62];
+#pragma unroll
+        for (int i = 1; i <= 25; i++) best = min(best, max(s[36 + i], sK[1][25 - i][sl_p3]));  // private x0+3
+        const float m = key2f(best);
+        out[o + 1] = dst.acc ? out[o + 1] + m : m;
+    }
+}
+
+void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);
+
+static bool median_flat_ok(int Z, int Y, int X, int nf)
+{
+    const long long n = (long long)Z * Y * X;
+    return X >= 8 && n < (1ll << 32) && nf >= 1 && nf <= 3;
+}
+
+bool median_can_accumulate(int Z, int Y, int X)
+{
+    static const char *env = getenv("FR3D_MEDIAN");
+    return (!env || atoi(env) == 0) && median_flat_ok(Z, Y, X, 3);
+}
+
+// nf fields of one volume (field f at in + f*fstride) in one launch; out[f] = median, or out[f] += median.
+void launch_median5_fields(hipStream_t st, const float *in, long long fstride, int nf, int Z, int Y, int X,
+                           float *const *out, bool accumulate)
+{
+    static const char *env = getenv("FR3D_MEDIAN");  // A/B aid: 1 one output per thread, 2 pairs without LDS, 3 row tiles
+    const int mode = env ? atoi(env) : 0;
+    if (mode == 0 && median_flat_ok(Z, Y, X, nf)) {
+        MedianDst d;
+        for (int f = 0; f < 3; f++) d.p[f] = f < nf ? out[f] : nullptr;
+        d.acc = accumulate ? 1 : 0;
+        const unsigned npairs = (unsigned)((long long)Z * Y * ((X + 1) / 2));
+        hipLaunchKernelGGL(k_median5_flat, dim3(cdiv((long long)npairs, MF_T), nf), dim3(MF_T), 0, st, in, fstride, Z, Y, X,
+                           npairs, d);
+        FR3D_LAUNCH_CHECK();
+        return;
+    }
+    FR3D_CHECK(!accumulate, "internal: accumulating median needs the flattened kernel");
+    for (int f = 0; f < nf; f++) launch_median5(st, in + (size_t)f * fstride, Z, Y, X, out[f]);
+}
+
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out)
 {
     static const char *env = getenv("FR3D_MEDIAN");  // A/B aid: 1 = one output per thread, 2 = pairs without LDS
     const int mode = env ? atoi(env) : 0;
-    if (mode == 1) {
+    if (mode == 0 && median_flat_ok(Z, Y, X, 1)) {
+        float *o[1] = {out};
+        launch_median5_fields(st, in, 0, 1, Z, Y, X, o, false);
+    } else if (mode == 1) {
         long long total = (long long)Z * Y * X;
         hipLaunchKernelGGL(k_median5, dim3(cdiv(total, 256)), dim3(256), 0, st, in, Z, Y, X, out);
         FR3D_LAUNCH_CHECK();

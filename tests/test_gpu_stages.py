@@ -153,12 +153,35 @@ def test_median_vs_reference_golden(hip):
         assert np.array_equal(got, g[k + "_med"].astype(np.float32))
 
 
-@pytest.mark.parametrize("shape", [(6, 6, 6), (7, 33, 65), (12, 9, 130)])
+@pytest.mark.parametrize("shape", [(6, 6, 6), (7, 33, 65), (12, 9, 130), (6, 7, 8), (9, 6, 9), (6, 7, 7),
+                                   (6, 11, 517), (6, 10, 1030), (40, 41, 43)])
 def test_median_bit_exact_vs_oracle(hip, oracle, shape):
+    """Row tiles (X < 8) and the flattened kernel: rows that start, end and break anywhere inside a workgroup, odd and
+    even widths, rows longer than one workgroup (its neighbour columns come from the extra sorting pass)."""
     rng = np.random.default_rng(3)
     x = rng.standard_normal(shape).astype(np.float32)
     x[1, 2, 3] = x[2, 2, 2]  # ties
     assert np.array_equal(hip.median_filter5(x), oracle.median5(x).astype(np.float32))
+
+
+def test_fused_median_update_is_bit_identical_to_separate_launches(hip):
+    """The engine's default tail of a level (one launch: medians of du, dv, dw added to the flow) against the
+    separate per-field median + accumulate launches (FR3D_MEDIAN=3, read at the library's first use, hence the
+    child process): the whole get_displacement result must agree bit for bit."""
+    import os, subprocess, sys, hashlib
+    code = ("import numpy as np, hashlib, flowreg3d_amd as fr\n"
+            "from flowreg3d_amd import synthetic\n"
+            "f, m, _ = synthetic.make_pair((24, 45, 51), seed=5)\n"
+            "w = fr.get_displacement(f, m, alpha=(0.25, 0.25, 0.25), iterations=12, update_lag=5, levels=3, a_smooth=1.0)\n"
+            "print('HASH', hashlib.sha256(np.ascontiguousarray(w).tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("0", "3"):
+        env = dict(os.environ, FR3D_MEDIAN=mode, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+    assert out["0"] == out["3"]
 
 
 def test_warp_survives_nan_and_huge_displacements(hip):
