@@ -359,16 +359,43 @@ static void resize3d(Engine &e, const float *src, int cs, int co, int D, int H, 
         sigy = sy < 1.0 ? sigma_coeff / sy : 0.0;
         sigz = sz < 1.0 ? sigma_coeff / sz : 0.0;
     }
-    const DevTable &tx = e.table(W, ow, sigx);
-    const DevTable &ty = e.table(H, oh, sigy);
-    const DevTable &tz = e.table(D, od, sigz);
-    float *t1 = e.f32("rs_t1", (size_t)D * H * ow);
-    float *t2 = e.f32("rs_t2", (size_t)D * oh * ow);
-    double bytes = 4.0 * ((double)D * H * W + 2.0 * D * H * ow + 2.0 * D * oh * ow + (double)od * oh * ow);
-    Span sp(e, FR3D_K_RESIZE, bytes, 3, (long long)od * oh * ow);
-    launch_resize_pass(e.st, src, cs, co, D, H, W, 2, ow, tx.idx, tx.wt, tx.P, t1);
-    launch_resize_pass(e.st, t1, 1, 0, D, H, ow, 1, oh, ty.idx, ty.wt, ty.P, t2);
-    launch_resize_pass(e.st, t2, 1, 0, D, oh, ow, 0, od, tz.idx, tz.wt, tz.P, dst);
+    // A pass whose axis keeps its length without smoothing has the taps (0, 0, 1, 0) exactly (Keys' kernel at
+    // -2, -1, 0, 1): its output is its input, so it is skipped (finite inputs; the x pass also gathers the
+    // channel out of an interleaved source, so it only goes when the source is planar).
+    const bool idx_ = W == ow && sigx == 0.0 && cs == 1, idy_ = H == oh && sigy == 0.0, idz_ = D == od && sigz == 0.0;
+    const float *cur = src;
+    int ccs = cs, cco = co;
+    double bytes = 0.0;
+    int passes = 0;
+    Span sp(e, FR3D_K_RESIZE, 0, 0, (long long)od * oh * ow);
+    if (!idx_) {
+        const DevTable &tx = e.table(W, ow, sigx);
+        float *o = (idy_ && idz_) ? dst : e.f32("rs_t1", (size_t)D * H * ow);
+        launch_resize_pass(e.st, cur, ccs, cco, D, H, W, 2, ow, tx.idx, tx.wt, tx.P, o);
+        bytes += 4.0 * ((double)D * H * W + (double)D * H * ow);
+        passes++;
+        cur = o; ccs = 1; cco = 0;
+    }
+    if (!idy_) {
+        const DevTable &ty = e.table(H, oh, sigy);
+        float *o = idz_ ? dst : e.f32("rs_t2", (size_t)D * oh * ow);
+        launch_resize_pass(e.st, cur, 1, 0, D, H, ow, 1, oh, ty.idx, ty.wt, ty.P, o);
+        bytes += 4.0 * ((double)D * H * ow + (double)D * oh * ow);
+        passes++;
+        cur = o;
+    }
+    if (!idz_) {
+        const DevTable &tz = e.table(D, od, sigz);
+        launch_resize_pass(e.st, cur, 1, 0, D, oh, ow, 0, od, tz.idx, tz.wt, tz.P, dst);
+        bytes += 4.0 * ((double)D * oh * ow + (double)od * oh * ow);
+        passes++;
+        cur = dst;
+    }
+    if (cur != dst) {  // all three axes unchanged: a copy
+        FR3D_HIP(hipMemcpyAsync(dst, src, (size_t)od * oh * ow * sizeof(float), hipMemcpyDeviceToDevice, e.st));
+        bytes += 8.0 * (double)od * oh * ow;
+    }
+    sp.add(bytes, passes, 0);
 }
 
 // cubic warp of one channel
@@ -377,10 +404,16 @@ static void warp_cubic_chan(Engine &e, const TV *vol, int vcs, int vco, const TF
                             const TF *pw, int fs, double hx, double hy, double hz, const TR *ref,
                             int Z, int Y, int X, TO *out, int ocs, int oco)
 {
-    const int npad = 12;
+    const bool compact = prefilter_compact_ok(Z, Y, X);
+    const int npad = compact ? 2 : 12;  // stored pad (the filter always runs over SciPy's 12)
     const size_t np = (size_t)(Z + 2 * npad) * (Y + 2 * npad) * (X + 2 * npad);
     double *coef = e.f64("warp_coef", np);
-    {
+    if (compact) {
+        const double N = (double)Z * Y * X, s1 = (double)(Z + 4) * Y * X, s2 = (double)(Z + 4) * (Y + 4) * X;
+        Span sp(e, FR3D_K_PREFILTER, sizeof(TV) * N + 24.0 * s1 + 8.0 * s1 + 24.0 * s2 + 8.0 * s2 + 24.0 * np, 3, (long long)np);
+        double *tmp = e.f64("warp_tmp", (size_t)(Z + 4) * (Y + 4) * X);
+        launch_prefilter3_compact<TV>(e.st, vol, vcs, vco, Z, Y, X, coef, tmp);
+    } else {
         Span sp(e, FR3D_K_PREFILTER, 8.0 * np * 7.0, 4, (long long)np);
         launch_pad_edge<TV>(e.st, vol, vcs, vco, Z, Y, X, npad, coef);
         launch_prefilter3(e.st, coef, Z + 2 * npad, Y + 2 * npad, X + 2 * npad);
@@ -503,8 +536,14 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         for (int b = nb; b < (int)nres; b++)  // reserved slots: allocate now, not inside a later timed batch
             for (int d = 0; d < 3; d++) (void)e.f32(std::string("uvw") + char('0' + d) + sfx + std::to_string(b), nl);
         for (int b = 0; b < nb; b++) {
-            float *f2l = e.f32("f2l", nl * C);
-            for (int c = 0; c < C; c++) resize3d(e, moving[b], C, c, Z, Y, X, lz, ly, lx, f2l + (size_t)c * nl);
+            // the moving image on this level; at full resolution the resampler is the identity (see resize3d) and
+            // a single-channel volume is read where it lies
+            const float *f2l = moving[b];
+            if (!(C == 1 && lz == Z && ly == Y && lx == X)) {
+                float *buf = e.f32("f2l", nl * C);
+                for (int c = 0; c < C; c++) resize3d(e, moving[b], C, c, Z, Y, X, lz, ly, lx, buf + (size_t)c * nl);
+                f2l = buf;
+            }
 
             // level flow (interior; ghosts are the edge pad of :88-89, implied)
             float **u = &uvw[3 * b], **up = &uvw_prev[3 * b];
@@ -702,9 +741,9 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
     // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
     const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0) + nfin * 4.0 * 9.0;
     // volume-independent scratch of the finest level: tensor/Laplacian staging (15, a_smooth != 1 only), moving
-    // level and its warp (2C), fp64 spline coefficients on the padded grid (~2.5), increments and their median (6),
+    // level and its warp (2C), fp64 spline coefficients and the y-pass scratch (~4.2), increments and their median (6),
     // reference and weight pyramids (~4C)
-    const double scratch = nfin * 4.0 * ((g_fast_path ? 0.0 : 15.0) + 2.0 * C + 2.5 + 6.0 + 4.0 * C) * (g_fp64_storage && !g_fast_path ? 1.5 : 1.0);
+    const double scratch = nfin * 4.0 * ((g_fast_path ? 0.0 : 15.0) + 2.0 * C + 4.2 + 6.0 + 4.0 * C) * (g_fp64_storage && !g_fast_path ? 1.5 : 1.0);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         // what the solver slabs may occupy: the memory that is free now plus what the engine already

@@ -197,6 +197,10 @@ template <typename T>
 void launch_pad_edge(hipStream_t st, const T *src, int cs, int co, int Z, int Y, int X, int npad,
                      double *dst);
 void launch_prefilter3(hipStream_t st, double *c, int PZ, int PY, int PX);
+// pad-free form (k_warp.hip, 2b): coefficients -2 .. N+1 per axis, coef (Z+4,Y+4,X+4), tmp (Z+4)(Y+4)X doubles
+bool prefilter_compact_ok(int Z, int Y, int X);
+template <typename T>
+void launch_prefilter3_compact(hipStream_t st, const T *vol, int cs, int co, int Z, int Y, int X, double *coef, double *tmp);
 // flow components pu/pv/pw with element stride fs; displacement = value / h (per axis).  TO = float
 // inside the pyramid; the executor tail writes the raw volume's own element type (OutCast in k_warp.hip)
 template <typename TF, typename TR, typename TO>

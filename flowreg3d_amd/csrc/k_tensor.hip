@@ -12,55 +12,116 @@ namespace fr3d {
 struct Img {
     const float *p;
     int Z, Y, X;
-    __device__ __forceinline__ double at(int z, int y, int x) const
-    {
-        z = z < 0 ? 0 : (z >= Z ? Z - 1 : z);
-        y = y < 0 ? 0 : (y >= Y ? Y - 1 : y);
-        x = x < 0 ? 0 : (x >= X ? X - 1 : x);
-        return (double)p[((size_t)z * Y + y) * X + x];
-    }
 };
 
 __device__ __forceinline__ int cl(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+// Grid spacings of the level with their reciprocals (host side, IEEE division: correctly rounded).
+struct TensorScale {
+    double tx, ty, tz, hx2, hy2, hz2;        // 2h and h^2 per axis (core/optical_flow_3d.py:105-118)
+    double rtx, rty, rtz, rhx2, rhy2, rhz2;  // RN(1/.) of the six divisors
+    int unit;                                // hx = hy = hz = 1 (the full-resolution level): x/2 = 0.5x, x/1 = x, exactly
+};
+inline TensorScale tensor_scale(double hz, double hy, double hx)
+{
+    TensorScale t;
+    t.tx = 2.0 * hx; t.ty = 2.0 * hy; t.tz = 2.0 * hz;
+    t.hx2 = hx * hx; t.hy2 = hy * hy; t.hz2 = hz * hz;
+    t.rtx = 1.0 / t.tx; t.rty = 1.0 / t.ty; t.rtz = 1.0 / t.tz;
+    t.rhx2 = 1.0 / t.hx2; t.rhy2 = 1.0 / t.hy2; t.rhz2 = 1.0 / t.hz2;
+    t.unit = hx == 1.0 && hy == 1.0 && hz == 1.0;
+    return t;
+}
+
+// a / b, correctly rounded, from y = RN(1/b): q0 = RN(a*y) is within 2 ulp of a/b, one residual step makes it
+// faithful, and a faithful quotient corrected once more with the exact FMA residual is the correctly rounded one
+// (Markstein's theorem; needs y correctly rounded -- it comes from the host's IEEE division -- and no
+// overflow/underflow, which fp32 image values over grid spacings of order 1 cannot reach).  5 instructions
+// instead of the ~12 of a full fp64 division; 24 of the 27 divisions per voxel divide by a level constant.
+// Differs from a true division only for infinite a (NaN instead of inf) and in the sign of a zero quotient.
+template <bool UNIT>
+__device__ __forceinline__ double divc(double a, double b, double y)
+{
+    if constexpr (UNIT) return a * y;  // y is 0.5 or 1: exact
+    const double q0 = a * y;
+    const double q1 = fma(fma(-b, q0, a), y, q0);
+    return fma(fma(-b, q1, a), y, q1);
+}
+
+// The 19 samples of one image that the derivatives of one voxel read: centre, 6 face and 12 edge neighbours,
+// every index clamped (the symmetric pads / re-pads of :93-104 are clamped indices).
+struct Sten19 {
+    double c, xm, xp, ym, yp, zm, zp;
+    double ymxm, ymxp, ypxm, ypxp;  // (z, y-+1, x-+1)
+    double zmxm, zmxp, zpxm, zpxp;  // (z-+1, y, x-+1)
+    double zmym, zmyp, zpym, zpyp;  // (z-+1, y-+1, x)
+};
+struct StenIdx {
+    size_t zb[3];     // slice bases of z-1, z, z+1 (clamped)
+    unsigned yo[3];   // row offsets inside a slice of y-1, y, y+1 (clamped)
+    unsigned xo[3];   // x-1, x, x+1 (clamped)
+};
+__device__ __forceinline__ StenIdx sten_index(int Z, int Y, int X, int z, int y, int x)
+{
+    StenIdx s;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        s.zb[q] = (size_t)cl(z + q - 1, Z) * ((size_t)Y * X);
+        s.yo[q] = (unsigned)cl(y + q - 1, Y) * (unsigned)X;
+        s.xo[q] = (unsigned)cl(x + q - 1, X);
+    }
+    return s;
+}
+__device__ __forceinline__ Sten19 sten_fetch(const float *__restrict__ p, const StenIdx &i)
+{
+    auto at = [&](int zi, int yi, int xi) { return (double)p[i.zb[zi] + (i.yo[yi] + i.xo[xi])]; };
+    Sten19 s;
+    s.c = at(1, 1, 1);
+    s.xm = at(1, 1, 0); s.xp = at(1, 1, 2);
+    s.ym = at(1, 0, 1); s.yp = at(1, 2, 1);
+    s.zm = at(0, 1, 1); s.zp = at(2, 1, 1);
+    s.ymxm = at(1, 0, 0); s.ymxp = at(1, 0, 2); s.ypxm = at(1, 2, 0); s.ypxp = at(1, 2, 2);
+    s.zmxm = at(0, 1, 0); s.zmxp = at(0, 1, 2); s.zpxm = at(2, 1, 0); s.zpxp = at(2, 1, 2);
+    s.zmym = at(0, 0, 1); s.zmyp = at(0, 2, 1); s.zpym = at(2, 0, 1); s.zpyp = at(2, 2, 1);
+    return s;
+}
 
 // Derivatives and normalisers of one voxel (core/optical_flow_3d.py:92-132), fp64, reference operation order.
 struct TensorVox {
     double fxx, fyy, fzz, fxy, fxz, fyz, fxt, fyt, fzt, rx, ry, rz;
 };
-__device__ __forceinline__ TensorVox tensor_voxel(const Img &f1, const Img &f2, int z, int y, int x, double hz,
-                                                  double hy, double hx)
+template <bool UNIT>
+__device__ __forceinline__ TensorVox tensor_voxel_t(const Img &f1, const Img &f2, int z, int y, int x, const TensorScale &h)
 {
-    const int Z = f1.Z, Y = f1.Y, X = f1.X;
-    const double tx = 2.0 * hx, ty = 2.0 * hy, tz = 2.0 * hz;
-    // first derivatives at (zz,yy,xx), position clamped (symmetric re-pad of :101-104)
-    auto FX = [&](int zz, int yy, int xx) {
-        zz = cl(zz, Z); yy = cl(yy, Y); xx = cl(xx, X);
-        double g1 = (f1.at(zz, yy, xx + 1) - f1.at(zz, yy, xx - 1)) / tx;
-        double g2 = (f2.at(zz, yy, xx + 1) - f2.at(zz, yy, xx - 1)) / tx;
+    const StenIdx si = sten_index(f1.Z, f1.Y, f1.X, z, y, x);
+    const Sten19 a = sten_fetch(f1.p, si), b = sten_fetch(f2.p, si);
+    // first derivatives of the averaged image pair at a neighbour: 0.5 * (d f1 + d f2), each a central
+    // difference over 2h (:105-110); the neighbour's position is clamped like the samples
+    auto avg_d = [&](double a_hi, double a_lo, double b_hi, double b_lo, double t, double rt) {
+        const double g1 = divc<UNIT>(a_hi - a_lo, t, rt);
+        const double g2 = divc<UNIT>(b_hi - b_lo, t, rt);
         return 0.5 * (g1 + g2);
     };
-    auto FY = [&](int zz, int yy, int xx) {
-        zz = cl(zz, Z); yy = cl(yy, Y); xx = cl(xx, X);
-        double g1 = (f1.at(zz, yy + 1, xx) - f1.at(zz, yy - 1, xx)) / ty;
-        double g2 = (f2.at(zz, yy + 1, xx) - f2.at(zz, yy - 1, xx)) / ty;
-        return 0.5 * (g1 + g2);
-    };
-    auto FT = [&](int zz, int yy, int xx) { return f2.at(zz, yy, xx) - f1.at(zz, yy, xx); };
     TensorVox v;
-    v.fxy = (FX(z, y + 1, x) - FX(z, y - 1, x)) / ty;
-    v.fxz = (FX(z + 1, y, x) - FX(z - 1, y, x)) / tz;
-    v.fyz = (FY(z + 1, y, x) - FY(z - 1, y, x)) / tz;
-    v.fzt = (FT(z + 1, y, x) - FT(z - 1, y, x)) / tz;
-    v.fyt = (FT(z, y + 1, x) - FT(z, y - 1, x)) / ty;
-    v.fxt = (FT(z, y, x + 1) - FT(z, y, x - 1)) / tx;
-    const double hx2 = hx * hx, hy2 = hy * hy, hz2 = hz * hz;
-    double a0 = f1.at(z, y, x), b0 = f2.at(z, y, x);
-    double fxx1 = (f1.at(z, y, x - 1) - 2.0 * a0 + f1.at(z, y, x + 1)) / hx2;
-    double fxx2 = (f2.at(z, y, x - 1) - 2.0 * b0 + f2.at(z, y, x + 1)) / hx2;
-    double fyy1 = (f1.at(z, y - 1, x) - 2.0 * a0 + f1.at(z, y + 1, x)) / hy2;
-    double fyy2 = (f2.at(z, y - 1, x) - 2.0 * b0 + f2.at(z, y + 1, x)) / hy2;
-    double fzz1 = (f1.at(z - 1, y, x) - 2.0 * a0 + f1.at(z + 1, y, x)) / hz2;
-    double fzz2 = (f2.at(z - 1, y, x) - 2.0 * b0 + f2.at(z + 1, y, x)) / hz2;
+    // fx at (z, y+-1, x), (z+-1, y, x); fy at (z+-1, y, x); ft = f2 - f1 at the six face neighbours
+    const double fx_yp = avg_d(a.ypxp, a.ypxm, b.ypxp, b.ypxm, h.tx, h.rtx);
+    const double fx_ym = avg_d(a.ymxp, a.ymxm, b.ymxp, b.ymxm, h.tx, h.rtx);
+    const double fx_zp = avg_d(a.zpxp, a.zpxm, b.zpxp, b.zpxm, h.tx, h.rtx);
+    const double fx_zm = avg_d(a.zmxp, a.zmxm, b.zmxp, b.zmxm, h.tx, h.rtx);
+    const double fy_zp = avg_d(a.zpyp, a.zpym, b.zpyp, b.zpym, h.ty, h.rty);
+    const double fy_zm = avg_d(a.zmyp, a.zmym, b.zmyp, b.zmym, h.ty, h.rty);
+    v.fxy = divc<UNIT>(fx_yp - fx_ym, h.ty, h.rty);
+    v.fxz = divc<UNIT>(fx_zp - fx_zm, h.tz, h.rtz);
+    v.fyz = divc<UNIT>(fy_zp - fy_zm, h.tz, h.rtz);
+    v.fzt = divc<UNIT>((b.zp - a.zp) - (b.zm - a.zm), h.tz, h.rtz);
+    v.fyt = divc<UNIT>((b.yp - a.yp) - (b.ym - a.ym), h.ty, h.rty);
+    v.fxt = divc<UNIT>((b.xp - a.xp) - (b.xm - a.xm), h.tx, h.rtx);
+    const double fxx1 = divc<UNIT>(a.xm - 2.0 * a.c + a.xp, h.hx2, h.rhx2);
+    const double fxx2 = divc<UNIT>(b.xm - 2.0 * b.c + b.xp, h.hx2, h.rhx2);
+    const double fyy1 = divc<UNIT>(a.ym - 2.0 * a.c + a.yp, h.hy2, h.rhy2);
+    const double fyy2 = divc<UNIT>(b.ym - 2.0 * b.c + b.yp, h.hy2, h.rhy2);
+    const double fzz1 = divc<UNIT>(a.zm - 2.0 * a.c + a.zp, h.hz2, h.rhz2);
+    const double fzz2 = divc<UNIT>(b.zm - 2.0 * b.c + b.zp, h.hz2, h.rhz2);
     v.fxx = 0.5 * (fxx1 + fxx2);
     v.fyy = 0.5 * (fyy1 + fyy2);
     v.fzz = 0.5 * (fzz1 + fzz2);
@@ -71,6 +132,10 @@ __device__ __forceinline__ TensorVox tensor_voxel(const Img &f1, const Img &f2, 
     v.ry = 1.0 / (syn * syn + 1e-6);
     v.rz = 1.0 / (szn * szn + 1e-6);
     return v;
+}
+__device__ __forceinline__ TensorVox tensor_voxel(const Img &f1, const Img &f2, int z, int y, int x, const TensorScale &h)
+{
+    return h.unit ? tensor_voxel_t<true>(f1, f2, z, y, x, h) : tensor_voxel_t<false>(f1, f2, z, y, x, h);
 }
 // square-root factors: J = sum_k a_k a_k^T with a_k = sqrt(reg_k) * (f_kx, f_ky, f_kz, f_kt).
 // psi_data is evaluated from these (sum of three squared residuals) because the expanded
@@ -85,7 +150,7 @@ __device__ __forceinline__ void tensor_factors12(const TensorVox &v, double (&A)
 
 template <typename TA>
 __global__ void __launch_bounds__(256)
-k_motion_tensor(Img f1, Img f2, double hz, double hy, double hx, float *J11, float *J22,
+k_motion_tensor(Img f1, Img f2, TensorScale hs, float *J11, float *J22,
                 float *J33, float *J44, float *J12, float *J13, float *J23, float *J14, float *J24,
                 float *J34, TA *A, long long a_stride, int skewed, int Yp, long long plane)
 {
@@ -97,7 +162,7 @@ k_motion_tensor(Img f1, Img f2, double hz, double hy, double hx, float *J11, flo
     long long r = t / X;
     int y = (int)(r % Y);
     int z = (int)(r / Y);
-    const TensorVox v = tensor_voxel(f1, f2, z, y, x, hz, hy, hx);
+    const TensorVox v = tensor_voxel(f1, f2, z, y, x, hs);
     const double fxx = v.fxx, fyy = v.fyy, fzz = v.fzz, fxy = v.fxy, fxz = v.fxz, fyz = v.fyz, fxt = v.fxt, fyt = v.fyt,
                  fzt = v.fzt, rx = v.rx, ry = v.ry, rz = v.rz;
 
@@ -130,7 +195,7 @@ k_motion_tensor(Img f1, Img f2, double hz, double hy, double hx, float *J11, flo
 #define TPX 32
 template <typename TA, int TY>
 __global__ void __launch_bounds__(256)
-k_motion_tensor_rec(Img f1, Img f2, double hz, double hy, double hx, TA *__restrict__ dst, const Skew sk)
+k_motion_tensor_rec(Img f1, Img f2, TensorScale hs, TA *__restrict__ dst, const Skew sk)
 {
     __shared__ TA tile[12][TY][TPX + 2];  // pitch 34: a diagonal's elements fall into consecutive banks
     const int Y = f1.Y, X = f1.X;
@@ -141,7 +206,7 @@ k_motion_tensor_rec(Img f1, Img f2, double hz, double hy, double hx, TA *__restr
     for (int ly = grp; ly < TY; ly += 8) {
         const int y = y0 + ly, x = x0 + lane;
         if (y < Y && x < X) {
-            const TensorVox v = tensor_voxel(f1, f2, z, y, x, hz, hy, hx);
+            const TensorVox v = tensor_voxel(f1, f2, z, y, x, hs);
             double a12[12];
             tensor_factors12(v, a12);
 #pragma unroll
@@ -169,7 +234,7 @@ void launch_motion_tensor_rec(hipStream_t st, const float *f1, const float *f2, 
     FR3D_CHECK(sk.Z <= 65535, "motion tensor: z axis longer than 65535");
     Img a{f1, sk.Z, sk.Y, sk.X}, b{f2, sk.Z, sk.Y, sk.X};
     dim3 grid(cdiv(sk.X, TPX) * cdiv(sk.Y, TY), sk.Z);
-    hipLaunchKernelGGL((k_motion_tensor_rec<TA, TY>), grid, dim3(256), 0, st, a, b, hz, hy, hx, dst, sk);
+    hipLaunchKernelGGL((k_motion_tensor_rec<TA, TY>), grid, dim3(256), 0, st, a, b, tensor_scale(hz, hy, hx), dst, sk);
     FR3D_LAUNCH_CHECK();
 }
 template void launch_motion_tensor_rec<float>(hipStream_t, const float *, const float *, double, double, double, float *,
@@ -184,7 +249,7 @@ void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int 
 {
     long long total = (long long)Z * Y * X;
     Img a{f1, Z, Y, X}, b{f2, Z, Y, X};
-    hipLaunchKernelGGL(k_motion_tensor<TA>, dim3(cdiv(total, 256)), dim3(256), 0, st, a, b, hz, hy, hx,
+    hipLaunchKernelGGL(k_motion_tensor<TA>, dim3(cdiv(total, 256)), dim3(256), 0, st, a, b, tensor_scale(hz, hy, hx),
                        J[0], J[1], J[2], J[3], J[4], J[5], J[6], J[7], J[8], J[9], A, a_stride, sk ? 1 : 0,
                        sk ? sk->Yp : 0, sk ? sk->plane : 0LL);
     FR3D_LAUNCH_CHECK();

@@ -8,6 +8,8 @@
 //   3. 4x4x4 gather with fp32 coordinates         (ni_interpolation.c NI_GeometricTransform)
 // Each warp is done once per pyramid level, so it is kept reference-exact (fp64 coefficients)
 // rather than minimal in bytes; the bandwidth-critical kernel of the path is the SOR sweep.
+#include <cstdlib>
+
 #include "fr3d_internal.h"
 
 namespace fr3d {
@@ -48,6 +50,8 @@ template void launch_pad_edge<double>(hipStream_t, const double *, int, int, int
 template void launch_pad_edge<unsigned char>(hipStream_t, const unsigned char *, int, int, int, int, int, int, double *);
 template void launch_pad_edge<unsigned short>(hipStream_t, const unsigned short *, int, int, int, int, int, int, double *);
 template void launch_pad_edge<short>(hipStream_t, const short *, int, int, int, int, int, int, double *);
+
+static double zpow(int n) { return pow(SPL_POLE, (double)n); }
 
 // ---- 2. prefilter -----------------------------------------------------------------------------
 // One line in place.  `c` points at element 0, consecutive elements are `stride` apart.
@@ -231,8 +235,6 @@ k_prefilter_x_tiled(double *c, long long nrows, int n)
     }
 }
 
-static double zpow(int n) { return pow(SPL_POLE, (double)n); }
-
 void launch_prefilter3(hipStream_t st, double *c, int PZ, int PY, int PX)
 {
     // axis 0 (z): lines over (y,x), stride PY*PX
@@ -259,6 +261,304 @@ void launch_prefilter3(hipStream_t st, double *c, int PZ, int PY, int PX)
     }
     FR3D_LAUNCH_CHECK();
 }
+
+// ---- 2b. prefilter without the stored pad -------------------------------------------------------
+// SciPy pads the volume by 12 replicated voxels and filters the padded array (steps 1-2 above).  The gather
+// clips its coordinates to [0, N-1] first (core/optical_flow_3d.py:47-50), so it only ever reads coefficients
+// -1 .. N+1 of an axis: here every line is still filtered over its full padded length N+24, in the same
+// operation order, but the 12 pad samples of each end are the line's edge value held in a register, the pad
+// LINES (copies of the edge lines, filtered to copies of their results) are not computed at all, and only the
+// coefficients -2 .. N+1 are stored: z pass raw volume -> (Z+4, Y, X), y pass -> (Z+4, Y+4, X), x pass ->
+// (Z+4, Y+4, X+4).  Same coefficients bit for bit as the padded form on that range (the x pass leaves out
+// the |pole|^n terms of the initialisation exactly like k_prefilter_x_tiled), 95 instead of 140 bytes of
+// traffic per voxel at 256^3 and 0.80 of the coefficient footprint.  Needs N >= 41 per axis (the
+// initialisation sum then never reaches the in-place quirk of short lines); smaller volumes take the padded path.
+#define PFC_PAD 12   // SciPy's pad
+#define PFC_KEEP 2   // stored pad
+#define PFC_SKIP (PFC_PAD - PFC_KEEP)
+
+#define PFC_CH 16  // samples per trip; the loads of the NEXT trip are issued before the recursion of this one
+template <typename TS>
+__device__ __forceinline__ void spline_line_compact(const TS *__restrict__ s, long long sst, int N, double *__restrict__ o,
+                                                    long long ost, double z_n)
+{
+    const double z = SPL_POLE;
+    const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+    const int S = N + 2 * PFC_KEEP;
+    auto in = [&](int i) {  // sample i of the padded line
+        int k = i - PFC_PAD;
+        k = k < 0 ? 0 : (k > N - 1 ? N - 1 : k);
+        return (double)s[(long long)k * sst];
+    };
+    const int n = N + 2 * PFC_PAD;
+    // causal initialisation over the first 64 padded samples (spline_line above, n > 64)
+    const double x0 = in(0) * gain;
+    double acc = x0 + z_n * (in(n - 1) * gain);
+    double z_i = z;
+    for (int i0 = 1; i0 < 64; i0 += PFC_CH) {
+        double xi[PFC_CH], xr[PFC_CH];
+#pragma unroll
+        for (int q = 0; q < PFC_CH; q++) {
+            const int i = i0 + q < 64 ? i0 + q : 63;
+            xi[q] = in(i);
+            xr[q] = in(n - 1 - i);
+        }
+#pragma unroll
+        for (int q = 0; q < PFC_CH; q++)
+            if (i0 + q < 64) {
+                const double a = xi[q] * gain;
+                const double r = xr[q] * gain;
+                acc += z_i * (a + z_n * r);
+                z_i *= z;
+            }
+    }
+    acc *= z / (1.0 - z_n * z_n);
+    acc += x0;
+    double prev = acc;  // coefficient 0 of the padded line
+    // causal sweep: padded samples 1 .. PFC_SKIP-1 are the edge value, not stored
+#pragma unroll
+    for (int i = 1; i < PFC_SKIP; i++) {
+        double xi = x0;
+        xi += z * prev;
+        prev = xi;
+    }
+    // A thread walks its line alone and a level has about one wave of lines per SIMD, so nothing else hides
+    // the memory latency of a trip: the next trip's samples are requested before this trip's recursion runs.
+    double v[PFC_CH], vn[PFC_CH];
+#pragma unroll
+    for (int q = 0; q < PFC_CH; q++) v[q] = in((q < S ? q : S - 1) + PFC_SKIP);
+    for (int j0 = 0; j0 < S; j0 += PFC_CH) {
+        if (j0 + PFC_CH < S) {
+#pragma unroll
+            for (int q = 0; q < PFC_CH; q++) vn[q] = in((j0 + PFC_CH + q < S ? j0 + PFC_CH + q : S - 1) + PFC_SKIP);
+        }
+#pragma unroll
+        for (int q = 0; q < PFC_CH; q++)
+            if (j0 + q < S) {
+                double xi = v[q] * gain;
+                xi += z * prev;
+                o[(long long)(j0 + q) * ost] = xi;
+                prev = xi;
+            }
+#pragma unroll
+        for (int q = 0; q < PFC_CH; q++) v[q] = vn[q];
+    }
+    double tail[PFC_SKIP];  // the last PFC_SKIP padded samples: edge value again, kept for the way back
+    const double xN = in(n - 1) * gain;
+#pragma unroll
+    for (int q = 0; q < PFC_SKIP; q++) {
+        double xi = xN;
+        xi += z * prev;
+        tail[q] = xi;
+        prev = xi;
+    }
+    // anticausal sweep
+    prev *= z / (z - 1.0);
+#pragma unroll
+    for (int q = PFC_SKIP - 2; q >= 0; q--) prev = z * (prev - tail[q]);
+#pragma unroll
+    for (int q = 0; q < PFC_CH; q++) v[q] = o[(long long)(S - 1 - q >= 0 ? S - 1 - q : 0) * ost];
+    for (int j0 = S - 1; j0 >= 0; j0 -= PFC_CH) {
+        if (j0 - PFC_CH >= 0) {
+#pragma unroll
+            for (int q = 0; q < PFC_CH; q++) vn[q] = o[(long long)(j0 - PFC_CH - q >= 0 ? j0 - PFC_CH - q : 0) * ost];
+        }
+#pragma unroll
+        for (int q = 0; q < PFC_CH; q++)
+            if (j0 - q >= 0) {
+                const double w = z * (prev - v[q]);
+                o[(long long)(j0 - q) * ost] = w;
+                prev = w;
+            }
+#pragma unroll
+        for (int q = 0; q < PFC_CH; q++) v[q] = vn[q];
+    }
+}
+
+// lines enumerated as (outer, inner); sample k of a source line at (outer*so + inner*si + k*ss) * cs + co
+template <typename TS>
+__global__ void __launch_bounds__(64)
+k_prefilter_lines_compact(const TS *__restrict__ src, int cs, int co, long long so, long long si, long long ss,
+                          double *__restrict__ out, long long oo, long long oi, long long os, long long nlines,
+                          long long inner_n, int N, double z_n)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlines) return;
+    const long long inner = t % inner_n, outer = t / inner_n;
+    spline_line_compact<TS>(src + (outer * so + inner * si) * cs + co, ss * cs, N, out + outer * oo + inner * oi, os, z_n);
+}
+
+// x axis: rows (nrows, N) -> (nrows, N+4); one wave per 64 rows, each lane walks its own row in a 64x32 LDS
+// tile (global accesses stay 256-B row segments).  The next tile's row segments are requested into registers
+// before the lanes run the recursion over the current tile, so their latency overlaps it.  (One tile buffer:
+// with two, 34 KB of LDS per workgroup allow four workgroups per CU and a 256^3 level needs 1057.)
+__global__ void __launch_bounds__(64)
+k_prefilter_x_compact(const double *__restrict__ src, long long nrows, int N, double *__restrict__ out)
+{
+    __shared__ double tile[64][PF_TW + 1];
+    const double z = SPL_POLE;
+    const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+    const int S = N + 2 * PFC_KEEP;
+    const int lane = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * 64;
+    const int lr = lane >> 5, lc = lane & 31;
+    // rows 2q + lr of the tile; the last workgroup repeats its last row (clamped, unconditional loads)
+    const long long rleft = nrows - 1 - row0 - lr;
+    const int qmax = rleft >= 62 ? 31 : (int)(rleft < 0 ? 0 : rleft / 2);
+    const long long rbase = rleft < 0 ? nrows - 1 : row0 + lr;
+
+    // 32 row segments of a tile: element (2q + lr, lc) = p[row*len + clamp(col0 + lc, 0, len-1)]
+    auto gload = [&](double (&v)[32], const double *__restrict__ p, int len, int col0) {
+        int col = col0 + lc;
+        col = col < 0 ? 0 : (col > len - 1 ? len - 1 : col);
+        const double *__restrict__ b = p + rbase * len + col;
+        const unsigned step = 2u * (unsigned)len;
+#pragma unroll
+        for (int q = 0; q < 32; q++) v[q] = b[(unsigned)(q < qmax ? q : qmax) * step];
+    };
+    auto to_lds = [&](const double (&v)[32]) {
+#pragma unroll
+        for (int q = 0; q < 32; q++) tile[2 * q + lr][lc] = v[q];
+    };
+    auto gstore = [&](int col0) {
+        const int col = col0 + lc;
+        if (col < S) {
+            double *__restrict__ b = out + (row0 + lr) * S + col;
+            const unsigned step = 2u * (unsigned)S;
+#pragma unroll
+            for (int q = 0; q < 32; q++)
+                if (q <= qmax && rleft >= 0) b[(unsigned)q * step] = tile[2 * q + lr][lc];
+        }
+    };
+
+    double g[32];
+    // causal initialisation from the first 64 padded samples (two tiles; source column = padded index - 12)
+    double x0 = 0.0, acc = 0.0, z_i = z;
+    gload(g, src, N, -PFC_PAD);
+    for (int t = 0; t < 2; t++) {
+        to_lds(g);
+        __syncthreads();
+        if (t == 0) gload(g, src, N, PF_TW - PFC_PAD);
+        else gload(g, src, N, -PFC_KEEP);  // first tile of the causal sweep
+#pragma unroll
+        for (int q = 0; q < PF_TW; q++) {
+            const double xi = tile[lane][q] * gain;
+            if (t == 0 && q == 0) {
+                x0 = xi;
+                acc = xi;
+            } else {
+                acc += z_i * xi;
+                z_i *= z;
+            }
+        }
+        __syncthreads();
+    }
+    acc *= z;
+    acc += x0;
+    double prev = acc;
+#pragma unroll
+    for (int i = 1; i < PFC_SKIP; i++) {
+        double xi = x0;
+        xi += z * prev;
+        prev = xi;
+    }
+    const int ntiles = (S + PF_TW - 1) / PF_TW;
+    for (int t = 0; t < ntiles; t++) {  // stored column j <-> source column j - 2
+        to_lds(g);
+        __syncthreads();
+        if (t + 1 < ntiles) gload(g, src, N, (t + 1) * PF_TW - PFC_KEEP);
+        const int qn = S - t * PF_TW;
+        double c[PF_TW];
+#pragma unroll
+        for (int q = 0; q < PF_TW; q++) c[q] = tile[lane][q];
+#pragma unroll
+        for (int q = 0; q < PF_TW; q++) {
+            double xi = c[q] * gain;
+            xi += z * prev;
+            c[q] = xi;
+            prev = q < qn ? xi : prev;
+        }
+#pragma unroll
+        for (int q = 0; q < PF_TW; q++) tile[lane][q] = c[q];
+        __syncthreads();
+        gstore(t * PF_TW);
+        __syncthreads();
+    }
+    double tail[PFC_SKIP];
+    {
+        long long row = row0 + lane;
+        if (row > nrows - 1) row = nrows - 1;
+        const double xN = src[row * N + (N - 1)] * gain;
+#pragma unroll
+        for (int q = 0; q < PFC_SKIP; q++) {
+            double xi = xN;
+            xi += z * prev;
+            tail[q] = xi;
+            prev = xi;
+        }
+    }
+    prev *= z / (z - 1.0);
+#pragma unroll
+    for (int q = PFC_SKIP - 2; q >= 0; q--) prev = z * (prev - tail[q]);
+    gload(g, out, S, (ntiles - 1) * PF_TW);
+    for (int t = ntiles - 1; t >= 0; t--) {
+        to_lds(g);
+        __syncthreads();
+        if (t > 0) gload(g, out, S, (t - 1) * PF_TW);
+        const int qn = S - t * PF_TW;
+        double c[PF_TW];
+#pragma unroll
+        for (int q = 0; q < PF_TW; q++) c[q] = tile[lane][q];
+#pragma unroll
+        for (int q = PF_TW - 1; q >= 0; q--) {
+            const double v = z * (prev - c[q]);
+            c[q] = v;
+            prev = q < qn ? v : prev;
+        }
+#pragma unroll
+        for (int q = 0; q < PF_TW; q++) tile[lane][q] = c[q];
+        __syncthreads();
+        gstore(t * PF_TW);
+        __syncthreads();
+    }
+}
+
+bool prefilter_compact_ok(int Z, int Y, int X)
+{
+    static const char *env = getenv("FR3D_PREFILTER");  // A/B aid: "padded" forces the stored-pad form
+    if (env && env[0] == 'p') return false;
+    return Z >= 41 && Y >= 41 && X >= 41;
+}
+
+// vol (Z,Y,X) with channel stride/offset -> coef (Z+4, Y+4, X+4); tmp holds (Z+4)(Y+4)X doubles
+template <typename T>
+void launch_prefilter3_compact(hipStream_t st, const T *vol, int cs, int co, int Z, int Y, int X, double *coef, double *tmp)
+{
+    const int SZ = Z + 2 * PFC_KEEP, SY = Y + 2 * PFC_KEEP;
+    const long long yx = (long long)Y * X;
+    {   // z: lines over (y,x); raw volume -> coef viewed as (SZ, Y, X)
+        hipLaunchKernelGGL((k_prefilter_lines_compact<T>), dim3(cdiv(yx, 64)), dim3(64), 0, st, vol, cs, co, 0LL, 1LL, yx,
+                           coef, 0LL, 1LL, yx, yx, yx, Z, zpow(Z + 2 * PFC_PAD));
+        FR3D_LAUNCH_CHECK();
+    }
+    {   // y: lines over (z,x); (SZ, Y, X) -> tmp (SZ, SY, X)
+        const long long nl = (long long)SZ * X;
+        hipLaunchKernelGGL((k_prefilter_lines_compact<double>), dim3(cdiv(nl, 64)), dim3(64), 0, st, (const double *)coef, 1, 0,
+                           yx, 1LL, (long long)X, tmp, (long long)SY * X, 1LL, (long long)X, nl, (long long)X, Y,
+                           zpow(Y + 2 * PFC_PAD));
+        FR3D_LAUNCH_CHECK();
+    }
+    {   // x: rows (SZ*SY, X) -> coef (SZ, SY, X+4)
+        const long long nr = (long long)SZ * SY;
+        hipLaunchKernelGGL(k_prefilter_x_compact, dim3(cdiv(nr, 64)), dim3(64), 0, st, (const double *)tmp, nr, X, coef);
+        FR3D_LAUNCH_CHECK();
+    }
+}
+template void launch_prefilter3_compact<float>(hipStream_t, const float *, int, int, int, int, int, double *, double *);
+template void launch_prefilter3_compact<double>(hipStream_t, const double *, int, int, int, int, int, double *, double *);
+template void launch_prefilter3_compact<unsigned char>(hipStream_t, const unsigned char *, int, int, int, int, int, double *, double *);
+template void launch_prefilter3_compact<unsigned short>(hipStream_t, const unsigned short *, int, int, int, int, int, double *, double *);
+template void launch_prefilter3_compact<short>(hipStream_t, const short *, int, int, int, int, int, double *, double *);
 
 // ---- 3. gather --------------------------------------------------------------------------------
 // ni_splines.c get_spline_interpolation_weights(), order 3

@@ -66,6 +66,55 @@ def test_warp_long_axis_tiled_prefilter(hip, oracle):
     assert np.abs(got - want).max() <= 1.2e-7
 
 
+@pytest.mark.parametrize("shape,dtype", [((41, 47, 70), np.float32), ((44, 41, 131), np.float64), ((52, 66, 43), np.uint16)])
+def test_warp_pad_free_prefilter_vs_oracle(hip, oracle, shape, dtype):
+    """Every axis >= 41: the prefilter keeps the 12 pad samples in registers and stores coefficients -2 .. N+1 only
+    (k_warp.hip 2b).  Displacements up to 3 voxels, so edge voxels sample right at and beyond the border; two channels
+    (interleaved source) and a raw integer volume."""
+    rng = np.random.default_rng(11)
+    C = 2
+    if np.issubdtype(dtype, np.integer):
+        f2 = rng.integers(0, 60000, shape + (C,)).astype(dtype)
+        f1 = rng.integers(0, 60000, shape + (C,)).astype(np.float32)
+    else:
+        f2 = rng.random(shape + (C,)).astype(dtype)
+        f1 = rng.random(shape + (C,)).astype(dtype)
+    u, v, w = (rng.uniform(-3, 3, shape).astype(np.float32) for _ in range(3))
+    got = hip.imregister_wrapper(f2.astype(np.float32) if dtype == np.uint16 else f2, u, v, w, f1)
+    want = oracle.imregister_wrapper(f2.astype(np.float32) if dtype == np.uint16 else f2, u, v, w, f1)
+    scale = 60000.0 if dtype == np.uint16 else 1.0
+    assert np.abs(got - want).max() <= 1.2e-7 * scale * 4
+    assert (got != want).mean() < 0.01
+
+
+def test_pad_free_prefilter_is_bit_identical_to_the_padded_form(hip):
+    """Same warp with FR3D_PREFILTER=padded (SciPy's layout: 12 stored pad voxels per side) in a child process."""
+    import os, subprocess, sys
+    code = ("import numpy as np, hashlib, flowreg3d_amd as fr\n"
+            "rng = np.random.default_rng(4)\n"
+            "shape = (45, 58, 77)\n"
+            "f2 = rng.random(shape + (2,)).astype(np.float32); f1 = rng.random(shape + (2,)).astype(np.float32)\n"
+            "u, v, w = (rng.uniform(-4, 4, shape).astype(np.float32) for _ in range(3))\n"
+            "f2[:9] = 0.0\n"
+            "out = fr.imregister_wrapper(f2, u, v, w, f1)\n"
+            "from flowreg3d_amd.executor import HipExecutor3D\n"
+            "raw = rng.integers(0, 65535, (2,) + shape + (1,)).astype(np.uint16)\n"
+            "proc = (raw / 65535.0).astype(np.float32)\n"
+            "reg, fl = HipExecutor3D().process_batch(raw, proc, proc[0].astype(np.float64), proc[0], np.zeros(shape + (3,), np.float32),\n"
+            "    flow_params=dict(alpha=(1.0, 1.0, 1.0), iterations=4, levels=2, a_smooth=1.0))\n"
+            "assert reg.dtype == np.uint16\n"
+            "h = hashlib.sha256(np.ascontiguousarray(out).tobytes()); h.update(np.ascontiguousarray(reg).tobytes())\n"
+            "print('HASH', h.hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("compact", "padded"):
+        env = dict(os.environ, FR3D_PREFILTER=mode, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+    assert out["compact"] == out["padded"]
+
+
 def test_warp_identity_and_oob(hip):
     rng = np.random.default_rng(2)
     vol = rng.random((9, 10, 11), dtype=np.float32)
