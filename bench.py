@@ -15,7 +15,8 @@ kernel (HIP events on the engine's stream) and `cpu_baseline` (the C oracle on a
 core and all cores).  At N = 1 the default run adds two legs to the same line, after the timed region of
 the headline workload: `host_path` (NumPy arrays in, NumPy arrays out through fr3d_process_batch: the
 PCIe-inclusive rate of the drop-in entry, never `value`) and `cfg3` (the 512^3 six-level configuration,
-4 timed steps at lock-step batch 4, with its own `roofline`); `--no-extras` skips both.
+4 timed steps at lock-step batch 4, with its own `roofline`) and `a_smooth_0.5` (the psi_smooth solver path on
+the cfg2 geometry); `--no-extras` skips them.
 """
 import argparse
 import ctypes as C
@@ -41,9 +42,9 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def solver_kwargs(levels):
+def solver_kwargs(levels, a_smooth=1.0):
     return dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=100, min_level=0, levels=levels,
-                eta=0.8, a_smooth=1.0, a_data=0.45)
+                eta=0.8, a_smooth=a_smooth, a_data=0.45)
 
 
 class DevArray:
@@ -164,14 +165,16 @@ def resolved_mode(solver_fp64, nvox, channels=1):
     return 2 if (channels >= 2 or nvox > (1 << 25)) else 1
 
 
-def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, world, dist, dev_index, fast_inputs):
+def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, world, dist, dev_index, fast_inputs,
+            a_smooth=1.0):
     """Warm up, condition, time EXACTLY K steps (volumes per rank) of `workload`; -> dict of results.
     Inputs are generated once and are resident in HBM before the timed region starts."""
     from flowreg3d_amd.synthetic import fast_pair, flow_gt, texture
     Z, Y, X, levels, desc = WORKLOADS[workload]
     nv = Z * Y * X
     T = K + W
-    params = _lib.make_params(n_channels=1, solver_fp64=None if solver_fp64 < 0 else solver_fp64, **solver_kwargs(levels))
+    params = _lib.make_params(n_channels=1, solver_fp64=None if solver_fp64 < 0 else solver_fp64,
+                              **solver_kwargs(levels, a_smooth))
     mode = resolved_mode(solver_fp64, nv)
 
     def reference_volume():
@@ -331,6 +334,9 @@ def main():
                          "path); 0 fp32 storage+update, 1 fp32 storage with fp64 update arithmetic, 2 fp64 storage")
     ap.add_argument("--batch", type=int, default=0,
                     help="volumes solved in lock step per GPU (shared launches); 0 = 8 at 256^3, 4 at 512^3")
+    ap.add_argument("--a-smooth", type=float, default=1.0,
+                    help="smoothness exponent (1.0 = the pipeline's OFOptions default and every BASELINE configuration; any "
+                         "other value, e.g. get_displacement's own default 0.5, runs the psi_smooth solver path)")
     ap.add_argument("--condition", type=float, default=30.0,
                     help="seconds of untimed warm-up work before the timed steps (0 = only the W warm-up steps)")
     args = ap.parse_args()
@@ -368,7 +374,7 @@ def main():
     lib = _lib.init(dev_index)
     K, W = args.steps, args.warmup
     m = measure(lib, _lib, args.workload, K, W, args.batch, args.condition, args.solver_fp64, rank, world, dist,
-                dev_index, fast_inputs=args.workload == "cfg3")
+                dev_index, fast_inputs=args.workload == "cfg3", a_smooth=args.a_smooth)
 
     if rank == 0:
         elapsed = m["elapsed"]
@@ -395,7 +401,7 @@ def main():
             "dtype": "f32" if m["mode"] < 2 else "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {m['desc']}; iterations=100, update_lag=5, eta=0.8, "
-                                   "alpha=0.25, a_data=0.45, a_smooth=1; lexicographic-exact SOR",
+                                   f"alpha=0.25, a_data=0.45, a_smooth={args.a_smooth:g}; lexicographic-exact SOR",
                        "solver": SOLVER_NAMES[m["mode"]] + (" (library's automatic choice)" if args.solver_fp64 < 0 else ""),
                        "parity_mean_epe_vs_cpu_path": m["parity_mean_epe_vs_cpu"],
                        "volumes_per_gpu_per_step": 1, "lockstep_batch": m["batch_vols"],
@@ -426,6 +432,16 @@ def main():
                             "solver": SOLVER_NAMES[c3["mode"]] + (" (library's automatic choice)" if md < 0 else " (forced)"),
                             "parity_mean_epe_vs_cpu_path": c3["parity_mean_epe_vs_cpu"], "roofline": c3["roofline"],
                             "kernel_ms_per_step": c3["kernel_ms_per_step"], "roofline_stages": c3["roofline_stages"]}
+            # (3) the psi_smooth solver path (a_smooth != 1; get_displacement's own default is 0.5, no BASELINE
+            # configuration uses it): cfg2 geometry, same parameters otherwise
+            _lib.shutdown()
+            lib = _lib.init(dev_index)
+            sm = measure(lib, _lib, "cfg2", 4, 1, 0, 0.0, args.solver_fp64, 0, 1, None, dev_index, fast_inputs=True,
+                         a_smooth=0.5)
+            out["a_smooth_0.5"] = {"workload": "cfg2 geometry with a_smooth=0.5 (psi_smooth re-evaluated every iteration)",
+                                   "value": 4 / sm["elapsed"], "unit": "volumes/sec", "steps": 4, "warmup": 1,
+                                   "ms_per_step": 1e3 * sm["elapsed"] / 4, "lockstep_batch": sm["batch_vols"],
+                                   "solver": SOLVER_NAMES[sm["mode"]], "kernel_ms_per_step": sm["kernel_ms_per_step"]}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -5,6 +5,8 @@
 // reference's operation order, so the fp64 tensor is bit-identical to NumPy's before it is
 // rounded once to the fp32 storage the solver streams.  Radius-2 footprint, served by L1/L2.
 // Output either natural (Z,Y,X) or directly in the solver's skewed layout.
+#include <cstdlib>
+
 #include "fr3d_internal.h"
 
 namespace fr3d {
@@ -195,7 +197,7 @@ k_motion_tensor(Img f1, Img f2, TensorScale hs, float *J11, float *J22,
 #define TPX 32
 template <typename TA, int TY>
 __global__ void __launch_bounds__(256)
-k_motion_tensor_rec(Img f1, Img f2, TensorScale hs, TA *__restrict__ dst, const Skew sk)
+k_motion_tensor_rec(Img f1, Img f2, TensorScale hs, TA *__restrict__ dst, const Skew sk, int dbg)
 {
     __shared__ TA tile[12][TY][TPX + 2];  // pitch 34: a diagonal's elements fall into consecutive banks
     const int Y = f1.Y, X = f1.X;
@@ -205,7 +207,7 @@ k_motion_tensor_rec(Img f1, Img f2, TensorScale hs, TA *__restrict__ dst, const 
     const int lane = threadIdx.x % TPX, grp = threadIdx.x / TPX;
     for (int ly = grp; ly < TY; ly += 8) {
         const int y = y0 + ly, x = x0 + lane;
-        if (y < Y && x < X) {
+        if (y < Y && x < X && !(dbg & 1)) {
             const TensorVox v = tensor_voxel(f1, f2, z, y, x, hs);
             double a12[12];
             tensor_factors12(v, a12);
@@ -218,7 +220,7 @@ k_motion_tensor_rec(Img f1, Img f2, TensorScale hs, TA *__restrict__ dst, const 
     for (int d = grp; d < ND; d += 8) {
         const int ly = lane, lx = d - lane;
         const int y = y0 + ly, x = x0 + lx;
-        if (ly < TY && lx >= 0 && lx < TPX && y < Y && x < X) {
+        if (ly < TY && lx >= 0 && lx < TPX && y < Y && x < X && !(dbg & 2)) {
             TA *o = dst + (size_t)sk_index(sk, z, y, x) * 12;
 #pragma unroll
             for (int q = 0; q < 12; q++) o[q] = tile[q][ly][lx];
@@ -233,8 +235,15 @@ void launch_motion_tensor_rec(hipStream_t st, const float *f1, const float *f2, 
     constexpr int TY = sizeof(TA) == 8 ? 16 : 32;  // 12 x TY x 34 values of LDS
     FR3D_CHECK(sk.Z <= 65535, "motion tensor: z axis longer than 65535");
     Img a{f1, sk.Z, sk.Y, sk.X}, b{f2, sk.Z, sk.Y, sk.X};
+    static const char *env = getenv("FR3D_TENSOR_DBG");
+    const int dbg = env ? atoi(env) : 0;
+    if (dbg & 4) {
+        dim3 grid(cdiv(sk.X, TPX) * cdiv(sk.Y, 16), sk.Z);
+        hipLaunchKernelGGL((k_motion_tensor_rec<TA, 16>), grid, dim3(256), 0, st, a, b, tensor_scale(hz, hy, hx), dst, sk, dbg);
+        return;
+    }
     dim3 grid(cdiv(sk.X, TPX) * cdiv(sk.Y, TY), sk.Z);
-    hipLaunchKernelGGL((k_motion_tensor_rec<TA, TY>), grid, dim3(256), 0, st, a, b, tensor_scale(hz, hy, hx), dst, sk);
+    hipLaunchKernelGGL((k_motion_tensor_rec<TA, TY>), grid, dim3(256), 0, st, a, b, tensor_scale(hz, hy, hx), dst, sk, dbg);
     FR3D_LAUNCH_CHECK();
 }
 template void launch_motion_tensor_rec<float>(hipStream_t, const float *, const float *, double, double, double, float *,
