@@ -488,8 +488,8 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         const float *f1l = rp.f1[li];
 
         // solver operands in the skewed layout, one slab per volume of the batch
-        // a_smooth == 1: compact skewed layout, records (k_sor.hip); otherwise the a_smooth != 1 kernels
-        // (k_sor_smooth.hip) on the pitched layout with one array per operand.  Both fill the same slabs.
+        // a_smooth == 1: compact skewed layout (k_sor.hip); otherwise the a_smooth != 1 kernels (k_sor_smooth.hip)
+        // on the pitched layout.  Both read records and fill the same slabs.
         const bool fast = p.a_smooth == 1.0;
         const Skew sk = fast ? e.compact_skew(lz, ly, lx) : make_skew(lz, ly, lx);
         const size_t ns = (size_t)sk.total;
@@ -523,12 +523,8 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         a.d = dbuf;
         {
             Span sp(e, FR3D_K_OTHER, 0, 0, 0);
-            if (fast) {
-                for (int c = 0; c < C; c++) launch_skew_pack<float, S>(e.st, rp.wl[li] + (size_t)c * nl, 0, wsk + (size_t)c * ns, 1, sk);
-            } else {
-                launch_skew_copy_n<float, S>(e.st, rp.wl[li], (long long)nl, wsk, (long long)ns, C, sk);
-            }
-            FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(S), e.st));
+            for (int c = 0; c < C; c++) launch_skew_pack<float, S>(e.st, rp.wl[li] + (size_t)c * nl, 0, wsk + (size_t)c * ns, 1, sk);
+            if (fast) FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(S), e.st));
         }
 
         const std::string sfx = flip ? "_a" : "_b";
@@ -565,30 +561,16 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 warped = wbuf;
             }
             {
-                // a_smooth == 1: factors and Laplacian terms go straight into the solver's records (LDS-tiled
-                // kernels); otherwise they are produced in the natural layout and moved by the tiled transpose
+                // factors (and for a_smooth == 1 the Laplacian terms; the psi_smooth kernels form their diffusion
+                // stencil from u,v,w themselves) go straight into the solver's records (LDS-tiled kernels)
                 Span sp(e, FR3D_K_TENSOR, 4.0 * (2 + 12) * nl * C, C, (long long)nl * C);
-                S *nat = fast ? nullptr : (S *)e.bufs["JAL_nat" + sn].ensure(nl * 15 * sizeof(S));
                 for (int c = 0; c < C; c++) {
                     // only the square-root factors are needed: the solver rebuilds the tensor from
                     // them on psi-update iterations and keeps its own frozen 3x3 system in between
-                    float *Jo[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
                     S *Adst = Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns;
-                    if (fast) {  // factors straight into the record layout
-                        launch_motion_tensor_rec<S>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, hz, hy, hx, Adst, sk);
-                    } else {
-                        launch_motion_tensor<S>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy,
-                                                hx, Jo, nat, (long long)nl, nullptr);
-                        launch_skew_copy_n<S, S>(e.st, nat, (long long)nl, Adst, (long long)ns, 12, sk);
-                    }
+                    launch_motion_tensor_rec<S>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, hz, hy, hx, Adst, sk);
                 }
-                if (fast) {
-                    launch_laplace_rec<S>(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Lbuf + (size_t)b * a.vsL);
-                } else {
-                    S *Ln = nat + 12 * nl;
-                    launch_laplace<S>(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Ln, Ln + nl, Ln + 2 * nl, true);
-                    launch_skew_copy_n<S, S>(e.st, Ln, (long long)nl, Lbuf + (size_t)b * a.vsL, (long long)ns, 3, sk);
-                }
+                if (fast) launch_laplace_rec<S>(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Lbuf + (size_t)b * a.vsL);
             }
         }
         a.iterations = p.iterations;
@@ -600,42 +582,52 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
             // in the solver's storage type: 4 (10C + 9) B with fp32 storage, twice that with fp64 storage
             sp.add((double)sizeof(S) * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
         } else {
-            // a_smooth != 1 (k_sor_smooth.hip): psi_smooth every iteration, triple-buffered increments,
-            // one volume at a time; the result is copied into the batch slab the common tail reads
+            // a_smooth != 1 (k_sor_smooth.hip): psi_smooth every iteration, triple-buffered increments; the volumes
+            // of the batch share the launches; the result is copied into the batch slab the common tail reads
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
-            S *smU = (S *)e.bufs["sm_U" + sn].ensure(ns * 3 * sizeof(S));
-            S *smD = (S *)e.bufs["sm_D" + sn].ensure(ns * 9 * sizeof(S));
-            S *smP = (S *)e.bufs["sm_P" + sn].ensure(ns * sizeof(S));
-            for (int b = 0; b < nb; b++) {
-                SmoothArgs<S> sa;
-                std::memset(&sa, 0, sizeof(sa));
-                sa.view.Z = lz; sa.view.Y = ly; sa.view.X = lx; sa.view.Yp = sk.Yp; sa.view.plane = sk.plane;
-                sa.view.hx = hx; sa.view.hy = hy; sa.view.hz = hz; sa.view.a_smooth = p.a_smooth;
-                for (int d = 0; d < 3; d++) {
-                    launch_skew_copy_n<float, S>(e.st, uvw[3 * b + d], 0, smU + (size_t)d * ns, 0, 1, sk);
-                    sa.view.U[d] = smU + (size_t)d * ns;
-                    for (int q = 0; q < 3; q++) sa.D[q][d] = smD + ((size_t)q * 3 + d) * ns;
-                }
-                FR3D_HIP(hipMemsetAsync(smD, 0, ns * 9 * sizeof(S), e.st));
-                sa.Ps = smP;
-                for (int q = 0; q < 9; q++) sa.M[q] = Mbuf + (size_t)b * a.vsM + (size_t)q * ns;
-                for (int c = 0; c < C; c++) {
-                    for (int q = 0; q < 12; q++)
-                        sa.A[q * FR3D_MAX_CHANNELS + c] = Abuf + (size_t)b * a.vsA + ((size_t)c * 12 + q) * ns;
-                    sa.weight[c] = a.weight[c];
-                    sa.a_data[c] = p.a_data[c];
-                }
-                sa.ax = a.ax; sa.ay = a.ay; sa.az = a.az;
-                sa.C = C;
-                sa.iterations = p.iterations;
-                sa.update_lag = p.update_lag;
-                sa.S_planes = sk.S;
-                long long n = launch_sor_smooth<S>(e.st, sa, e.sched(sk, p.iterations, SM_LAG));
-                if (p.iterations > 0)
-                    FR3D_HIP(hipMemcpyAsync(dbuf + (size_t)b * a.vsD, sa.D[(p.iterations - 1) % 3][0], ns * 3 * sizeof(S),
-                                            hipMemcpyDeviceToDevice, e.st));
-                sp.add((double)sizeof(S) * (10.0 * C + 9.0) * (double)nl * p.iterations, n, (long long)nl * p.iterations);
+            S *smU = (S *)e.bufs["sm_U" + sn].ensure(ns * 3 * nb * sizeof(S));
+            S *smD = (S *)e.bufs["sm_D" + sn].ensure(ns * 9 * nb * sizeof(S));
+            S *smP = (S *)e.bufs["sm_P" + sn].ensure(ns * nb * sizeof(S));
+            SmoothArgs<S> sa;
+            std::memset(&sa, 0, sizeof(sa));
+            sa.view.Z = lz; sa.view.Y = ly; sa.view.X = lx; sa.view.Yp = sk.Yp; sa.view.plane = sk.plane;
+            smooth_set_spacing(sa.view, hx, hy, hz);
+            sa.view.a_smooth = p.a_smooth;
+            sa.view.U = smU;
+            sa.nvol = nb;
+            sa.vsU = (long long)ns * 3; sa.vsD = (long long)ns * 3; sa.vsP = (long long)ns;
+            sa.vsM = a.vsM; sa.vsA = a.vsA;
+            for (int m = 0; m < 3; m++) sa.D[m] = smD + (size_t)m * 3 * ns * nb;
+            sa.Ps = smP;
+            sa.M = Mbuf;
+            for (int c = 0; c < C; c++) {
+                sa.A[c] = a.A[c];
+                sa.weight[c] = a.weight[c];
+                sa.a_data[c] = p.a_data[c];
             }
+            sa.ax = a.ax; sa.ay = a.ay; sa.az = a.az;
+            sa.C = C;
+            sa.iterations = p.iterations;
+            sa.update_lag = p.update_lag;
+            sa.S_planes = sk.S;
+            {
+                float *stage = e.f32("d_nat", nl * 3);  // the increments' scratch is free until the solver has run
+                for (int b = 0; b < nb; b++) {
+                    for (int d = 0; d < 3; d++)
+                        FR3D_HIP(hipMemcpyAsync(stage + (size_t)d * nl, uvw[3 * b + d], nl * sizeof(float), hipMemcpyDeviceToDevice, e.st));
+                    launch_skew_pack<float, S>(e.st, stage, (long long)nl, smU + (size_t)b * sa.vsU, 3, sk);
+                }
+            }
+            FR3D_HIP(hipMemsetAsync(smD, 0, ns * 9 * nb * sizeof(S), e.st));
+            long long n = launch_sor_smooth<S>(e.st, sa, e.sched(sk, p.iterations, SM_LAG));
+            if (p.iterations > 0) {
+                for (int b = 0; b < nb; b++)
+                    FR3D_HIP(hipMemcpyAsync(dbuf + (size_t)b * a.vsD, sa.D[(p.iterations - 1) % 3] + (size_t)b * sa.vsD,
+                                            ns * 3 * sizeof(S), hipMemcpyDeviceToDevice, e.st));
+            } else {
+                FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(S), e.st));
+            }
+            sp.add((double)sizeof(S) * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
         }
         // increments back to the natural layout, 5^3 median (:517-526), accumulate (:527-529)
         const bool med = std::min(lz, std::min(ly, lx)) > 5;
@@ -646,8 +638,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 Span sp(e, FR3D_K_OTHER, 0, 0, 0);
                 // increments leave the solver rounded to fp32: the next level (and the executor) cast to
                 // fp32 anyway (util/resize_util_3D.py:116, sequential_3d.py:150) and the median commutes with it
-                if (fast) launch_unskew_unpack<S, float>(e.st, dbuf + (size_t)b * a.vsD, dn, (long long)nl, 3, sk);
-                else launch_unskew_copy_n<S, float>(e.st, dbuf + (size_t)b * a.vsD, (long long)ns, dn, (long long)nl, 3, sk);
+                launch_unskew_unpack<S, float>(e.st, dbuf + (size_t)b * a.vsD, dn, (long long)nl, 3, sk);
             }
             if (med && median_can_accumulate(lz, ly, lx)) {
                 // one launch for du, dv, dw, the flow update u += median(du) fused (:517-529)
@@ -739,11 +730,11 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
     }
     const double nfin = (double)F.z * F.y * F.x;
     // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
-    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0) + nfin * 4.0 * 9.0;
-    // volume-independent scratch of the finest level: tensor/Laplacian staging (15, a_smooth != 1 only), moving
+    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0 + (g_fast_path ? 0.0 : 13.0)) + nfin * 4.0 * 9.0;
+    // volume-independent scratch of the finest level: moving
     // level and its warp (2C), fp64 spline coefficients and the y-pass scratch (~4.2), increments and their median (6),
     // reference and weight pyramids (~4C)
-    const double scratch = nfin * 4.0 * ((g_fast_path ? 0.0 : 15.0) + 2.0 * C + 4.2 + 6.0 + 4.0 * C) * (g_fp64_storage && !g_fast_path ? 1.5 : 1.0);
+    const double scratch = nfin * 4.0 * (2.0 * C + 4.2 + 6.0 + 4.0 * C);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         // what the solver slabs may occupy: the memory that is free now plus what the engine already
@@ -1552,7 +1543,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     FR3D_CHECK(iterations >= 0 && update_lag >= 1, "iterations >= 0 and update_lag >= 1 required");
     Engine &e = g_eng;
     const size_t n = (size_t)Z * Y * X;
-    const bool fast = a_smooth == 1.0;  // compact layout + records (k_sor.hip) / pitched layout, one array per operand
+    const bool fast = a_smooth == 1.0;  // compact layout (k_sor.hip) / pitched layout (k_sor_smooth.hip); records in both
     const Skew sk = fast ? e.compact_skew(Z, Y, X) : make_skew(Z, Y, X);
     const size_t ns = (size_t)sk.total;
     Staged s;
@@ -1576,42 +1567,38 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     // A arrives as (12, C, Z, Y, X): factor q of channel c at (q*C + c)*n
     for (int c = 0; c < C; c++) {
         float *Adst = Ask + (size_t)c * 12 * ns;
-        if (fast) launch_skew_pack<float, float>(e.st, dA + (size_t)c * n, (long long)C * n, Adst, 12, sk);
-        else launch_skew_copy_n<float, float>(e.st, dA + (size_t)c * n, (long long)C * n, Adst, (long long)ns, 12, sk);
+        launch_skew_pack<float, float>(e.st, dA + (size_t)c * n, (long long)C * n, Adst, 12, sk);
         a.A[c] = Adst;
-        if (fast) launch_skew_pack<float, float>(e.st, dW + (size_t)c * n, 0, wsk + (size_t)c * ns, 1, sk);
-        else launch_skew_copy_n<float, float>(e.st, dW + (size_t)c * n, 0, wsk + (size_t)c * ns, 0, 1, sk);
+        launch_skew_pack<float, float>(e.st, dW + (size_t)c * n, 0, wsk + (size_t)c * ns, 1, sk);
         a.weight[c] = wsk + (size_t)c * ns;
         a.a_data[c] = a_data[c];
     }
     a.ax = alpha3[0] / (hx * hx);
     a.ay = alpha3[1] / (hy * hy);
     a.az = alpha3[2] / (hz * hz);
-    launch_laplace<float>(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lnat, Lnat + n, Lnat + 2 * n, true);
-    if (fast) launch_skew_pack<float, float>(e.st, Lnat, (long long)n, Lb, 3, sk);
-    else launch_skew_copy_n<float, float>(e.st, Lnat, (long long)n, Lb, (long long)ns, 3, sk);
     FR3D_HIP(hipMemsetAsync(db, 0, ns * 3 * 4, e.st));
     a.iterations = iterations;
     a.update_lag = update_lag;
     if (fast) {
+        launch_laplace<float>(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lnat, Lnat + n, Lnat + 2 * n, true);
+        launch_skew_pack<float, float>(e.st, Lnat, (long long)n, Lb, 3, sk);
         launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
-        launch_unskew_unpack<float, float>(e.st, db, dn, (long long)n, 3, sk);
     } else {
         float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);
         SmoothArgs<float> sa;
         std::memset(&sa, 0, sizeof(sa));
         sa.view.Z = Z; sa.view.Y = Y; sa.view.X = X; sa.view.Yp = sk.Yp; sa.view.plane = sk.plane;
-        sa.view.hx = hx; sa.view.hy = hy; sa.view.hz = hz; sa.view.a_smooth = a_smooth;
-        launch_skew_copy_n<float, float>(e.st, dU, (long long)n, smU, (long long)ns, 3, sk);
+        smooth_set_spacing(sa.view, hx, hy, hz);
+        sa.view.a_smooth = a_smooth;
+        launch_skew_pack<float, float>(e.st, dU, (long long)n, smU, 3, sk);
         FR3D_HIP(hipMemsetAsync(smD, 0, ns * 9 * 4, e.st));
-        for (int d = 0; d < 3; d++) {
-            sa.view.U[d] = smU + (size_t)d * ns;
-            for (int q = 0; q < 3; q++) sa.D[q][d] = smD + ((size_t)q * 3 + d) * ns;
-        }
+        sa.view.U = smU;
+        sa.nvol = 1;
+        for (int m = 0; m < 3; m++) sa.D[m] = smD + (size_t)m * 3 * ns;
         sa.Ps = smP;
-        for (int q = 0; q < 9; q++) sa.M[q] = Msk + (size_t)q * ns;
+        sa.M = Msk;
         for (int c = 0; c < C; c++) {
-            for (int q = 0; q < 12; q++) sa.A[q * FR3D_MAX_CHANNELS + c] = Ask + ((size_t)c * 12 + q) * ns;
+            sa.A[c] = a.A[c];
             sa.weight[c] = a.weight[c];
             sa.a_data[c] = a_data[c];
         }
@@ -1619,9 +1606,9 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
         sa.C = C; sa.iterations = iterations; sa.update_lag = update_lag; sa.S_planes = sk.S;
         launch_sor_smooth<float>(e.st, sa, e.sched(sk, iterations, SM_LAG));
         if (iterations > 0)
-            FR3D_HIP(hipMemcpyAsync(db, sa.D[(iterations - 1) % 3][0], ns * 3 * 4, hipMemcpyDeviceToDevice, e.st));
-        launch_unskew_copy_n<float, float>(e.st, db, (long long)ns, dn, (long long)n, 3, sk);
+            FR3D_HIP(hipMemcpyAsync(db, sa.D[(iterations - 1) % 3], ns * 3 * 4, hipMemcpyDeviceToDevice, e.st));
     }
+    launch_unskew_unpack<float, float>(e.st, db, dn, (long long)n, 3, sk);
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 4, hipMemcpyDeviceToHost));
     FR3D_CATCH

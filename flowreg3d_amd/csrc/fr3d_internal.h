@@ -85,6 +85,18 @@ __host__ __device__ static inline long long sk_index(int X, int Yp, long long pl
     return (long long)(x + y + z) * plane + (long long)z * Yp + (y - sk_jm(X, x + y));
 }
 
+// a / b, correctly rounded, from y = RN(1/b) computed by the host's IEEE division: q0 = RN(a*y) is within 2 ulp
+// of a/b, one residual step makes it faithful, and a faithful quotient corrected once more with the exact FMA
+// residual is the correctly rounded one (Markstein's theorem; no overflow/underflow for image and flow values
+// over grid spacings of order 1).  5 instructions instead of the ~12 of a full fp64 division.  Differs from a
+// true division only for infinite a (NaN instead of inf) and in the sign of a zero quotient.
+__device__ __forceinline__ double div_by_const(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double q1 = fma(fma(-b, q0, a), y, q0);
+    return fma(fma(-b, q1, a), y, q1);
+}
+
 static inline Skew make_skew(int Z, int Y, int X)
 {
     Skew k;
@@ -160,26 +172,36 @@ using SorArgs = SorArgsT<float>;
 #define SM_LAG 4  // hyperplanes between consecutive in-flight iterations on this path
 template <typename S>
 struct SmoothView {
-    const S *U[3];   // u,v,w skewed (interior)
-    const S *Dm1[3]; // increments of iteration t-1
-    const S *Dm2[3]; // increments of iteration t-2 (ghost source)
+    const S *U;    // u,v,w skewed (interior), records of 3
+    const S *Dm1;  // increments of iteration t-1, records of 3
+    const S *Dm2;  // increments of iteration t-2 (ghost source)
     int Z, Y, X, Yp;
     long long plane;
-    double hx, hy, hz, a_smooth;
+    double tx, ty, tz, rtx, rty, rtz;  // 2h per axis and RN(1 / 2h) (div_by_const)
+    double a_smooth;
 };
 
+// Pitched skewed layout; every per-volume operand of a lock-step batch is `vs*` elements behind the previous
+// volume's (the kernel's blockIdx.y is the volume of the batch); `weight` is shared.
 template <typename S>
 struct SmoothArgs {
     SmoothView<S> view;      // U + geometry; Dm1/Dm2 are set per launch from `D`
-    S *D[3][3];              // [buffer][component], iteration t writes D[t % 3]
+    S *D[3];                 // increments, records of 3; iteration t writes D[t % 3]
     S *Ps;                   // psi_s of the iteration that will sweep next (in place per plane)
-    S *M[9];                 // frozen data-term system (M11,M22,M33,M12,M13,M23, b_u,b_v,b_w; b without L)
-    const S *A[12 * FR3D_MAX_CHANNELS];
+    S *M;                    // frozen data-term system, records of 9 (M11,M22,M33,M12,M13,M23, b_u,b_v,b_w; b without L)
+    const S *A[FR3D_MAX_CHANNELS];  // square-root factors, records of 12 per channel
     const S *weight[FR3D_MAX_CHANNELS];
+    long long vsU, vsD, vsP, vsM, vsA;
     double ax, ay, az;
     double a_data[FR3D_MAX_CHANNELS];
-    int C, iterations, update_lag, S_planes;
+    int C, iterations, update_lag, S_planes, nvol;
 };
+template <typename S>
+inline void smooth_set_spacing(SmoothView<S> &v, double hx, double hy, double hz)
+{
+    v.tx = 2.0 * hx; v.ty = 2.0 * hy; v.tz = 2.0 * hz;
+    v.rtx = 1.0 / v.tx; v.rty = 1.0 / v.ty; v.rtz = 1.0 / v.tz;
+}
 
 struct SorSched;
 template <typename S>

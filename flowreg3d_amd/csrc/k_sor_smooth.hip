@@ -18,28 +18,32 @@
 //    would otherwise diverge in the first and last wave of every row -- the surface voxels of both.
 //    fp64 arithmetic (the (u + du) - u differences cancel in fp32); not on any BASELINE configuration
 //    (OFOptions.a_smooth = 1.0), but get_displacement's own default.
+//  * operands are records like in k_sor.hip (u,v,w / du,dv,dw: 3 values, system: 9, factors: 12 per voxel
+//    contiguous, pitched skewed rows), so a neighbour costs three wide loads instead of seven dword loads, and
+//    the volumes of a lock-step batch share the launches (blockIdx.y = volume of the batch).
 #include <cstdlib>
 
 #include "fr3d_internal.h"
+#include "k_sor_core.h"
 
 namespace fr3d {
 
 #define SM_OMEGA 1.95
 
-// uu component `c` at padded-grid position (k,j,i) in [-1,Z] x [-1,Y] x [-1,X] (interior coordinates)
+// uu = u + du (three components) at padded-grid position (k,j,i) in [-1,Z] x [-1,Y] x [-1,X] (interior coordinates)
 template <typename S>
-__device__ __forceinline__ double uu_at(const SmoothView<S> &v, int c, int k, int j, int i)
+__device__ __forceinline__ void uu3_at(const SmoothView<S> &v, int k, int j, int i, double (&uu)[3])
 {
     const bool ghost = k < 0 || k >= v.Z || j < 0 || j >= v.Y || i < 0 || i >= v.X;
     const int kc = k < 0 ? 0 : (k >= v.Z ? v.Z - 1 : k);
     const int jc = j < 0 ? 0 : (j >= v.Y ? v.Y - 1 : j);
     const int ic = i < 0 ? 0 : (i >= v.X ? v.X - 1 : i);
-    const size_t o = (size_t)sk_index(v.X, v.Yp, v.plane, kc, jc, ic);
-    // both buffers are read and the value is selected: selecting the POINTER (v.Dm2[c] vs v.Dm1[c]) makes
-    // the compiler index the view structure with a run-time offset, which pins it in scratch memory
-    // and degrades every access through it to a flat load
-    const double d1 = (double)v.Dm1[c][o], d2 = (double)v.Dm2[c][o];
-    return (double)v.U[c][o] + (ghost ? d2 : d1);
+    const long long o = sk_index(v.X, v.Yp, v.plane, kc, jc, ic);
+    // both buffers are read and the value is selected: selecting the POINTER (v.Dm2 vs v.Dm1) would cost a
+    // 64-bit select per access and no load less
+    const Rec<S, 3> u = ldrec<S, 3>(v.U, o), d1 = ldrec<S, 3>(v.Dm1, o), d2 = ldrec<S, 3>(v.Dm2, o);
+#pragma unroll
+    for (int c = 0; c < 3; c++) uu[c] = (double)u.v[c] + (ghost ? (double)d2.v[c] : (double)d1.v[c]);
 }
 
 // nonlinearity_smoothness_3d at one padded position (indices clamped to the padded array,
@@ -51,12 +55,19 @@ __device__ __forceinline__ double psi_smooth_at(const SmoothView<S> &v, int k, i
     const int km = cl(k - 1, v.Z), kp = cl(k + 1, v.Z);
     const int jm = cl(j - 1, v.Y), jp = cl(j + 1, v.Y);
     const int im = cl(i - 1, v.X), ip = cl(i + 1, v.X);
+    double xp[3], xm[3], yp[3], ym[3], zp[3], zm[3];
+    uu3_at(v, k, j, ip, xp);
+    uu3_at(v, k, j, im, xm);
+    uu3_at(v, k, jp, i, yp);
+    uu3_at(v, k, jm, i, ym);
+    uu3_at(v, kp, j, i, zp);
+    uu3_at(v, km, j, i, zm);
     double g = 0.0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const double dx = (uu_at(v, c, k, j, ip) - uu_at(v, c, k, j, im)) / (2.0 * v.hx);
-        const double dy = (uu_at(v, c, k, jp, i) - uu_at(v, c, k, jm, i)) / (2.0 * v.hy);
-        const double dz = (uu_at(v, c, kp, j, i) - uu_at(v, c, km, j, i)) / (2.0 * v.hz);
+        const double dx = div_by_const(xp[c] - xm[c], v.tx, v.rtx);
+        const double dy = div_by_const(yp[c] - ym[c], v.ty, v.rty);
+        const double dz = div_by_const(zp[c] - zm[c], v.tz, v.rtz);
         g += dx * dx;
         g += dy * dy;
         g += dz * dz;
@@ -72,9 +83,17 @@ __device__ __forceinline__ double psi_smooth_at(const SmoothView<S> &v, int k, i
 // run-time value would move the pointer table to scratch memory and turn every access through it
 // into a flat load
 template <typename S>
-__device__ __forceinline__ S *pick_buffer(const SmoothArgs<S> &a, int m, int c)
+__device__ __forceinline__ S *pick_buffer(const SmoothArgs<S> &a, int m)
 {
-    return m == 0 ? a.D[0][c] : (m == 1 ? a.D[1][c] : a.D[2][c]);
+    return (m == 0 ? a.D[0] : (m == 1 ? a.D[1] : a.D[2])) + (size_t)blockIdx.y * a.vsD;
+}
+// the geometry + this volume's u,v,w; Dm1/Dm2 are set by the callers
+template <typename S>
+__device__ __forceinline__ SmoothView<S> volume_view(const SmoothArgs<S> &a)
+{
+    SmoothView<S> v = a.view;
+    v.U = a.view.U + (size_t)blockIdx.y * a.vsU;
+    return v;
 }
 
 // Thread -> voxel mapping shared by both kernels: the tile schedule of k_sor.hip with SM_LAG planes
@@ -157,24 +176,24 @@ __device__ __forceinline__ bool locate_surface(const SmoothArgs<S> &a, int b, in
 template <typename S, bool INTERIOR>
 __device__ __forceinline__ void psi_voxel(const SmoothArgs<S> &a, const SmoothPos &p)
 {
-    SmoothView<S> v = a.view;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        v.Dm1[c] = pick_buffer(a, (p.t + 2) % 3, c);  // (t-1) mod 3
-        v.Dm2[c] = pick_buffer(a, (p.t + 1) % 3, c);  // (t-2) mod 3
-    }
+    SmoothView<S> v = volume_view(a);
+    v.Dm1 = pick_buffer(a, (p.t + 2) % 3);  // (t-1) mod 3
+    v.Dm2 = pick_buffer(a, (p.t + 1) % 3);  // (t-2) mod 3
     double ps;
     if constexpr (INTERIOR) {
+        const S *U = v.U, *D = v.Dm1;
+        const Rec<S, 3> uxp = ldrec<S, 3>(U, p.xp), dxp = ldrec<S, 3>(D, p.xp), uxm = ldrec<S, 3>(U, p.xm), dxm = ldrec<S, 3>(D, p.xm);
+        const Rec<S, 3> uyp = ldrec<S, 3>(U, p.yp), dyp = ldrec<S, 3>(D, p.yp), uym = ldrec<S, 3>(U, p.ym), dym = ldrec<S, 3>(D, p.ym);
+        const Rec<S, 3> uzp = ldrec<S, 3>(U, p.zp), dzp = ldrec<S, 3>(D, p.zp), uzm = ldrec<S, 3>(U, p.zm), dzm = ldrec<S, 3>(D, p.zm);
         double g = 0.0;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const S *U = v.U[c], *D = v.Dm1[c];
-            const double xp = (double)U[p.xp] + (double)D[p.xp], xm = (double)U[p.xm] + (double)D[p.xm];
-            const double yp = (double)U[p.yp] + (double)D[p.yp], ym = (double)U[p.ym] + (double)D[p.ym];
-            const double zp = (double)U[p.zp] + (double)D[p.zp], zm = (double)U[p.zm] + (double)D[p.zm];
-            const double dx = (xp - xm) / (2.0 * v.hx);
-            const double dy = (yp - ym) / (2.0 * v.hy);
-            const double dz = (zp - zm) / (2.0 * v.hz);
+            const double xp = (double)uxp.v[c] + (double)dxp.v[c], xm = (double)uxm.v[c] + (double)dxm.v[c];
+            const double yp = (double)uyp.v[c] + (double)dyp.v[c], ym = (double)uym.v[c] + (double)dym.v[c];
+            const double zp = (double)uzp.v[c] + (double)dzp.v[c], zm = (double)uzm.v[c] + (double)dzm.v[c];
+            const double dx = div_by_const(xp - xm, v.tx, v.rtx);
+            const double dy = div_by_const(yp - ym, v.ty, v.rty);
+            const double dz = div_by_const(zp - zm, v.tz, v.rtz);
             g += dx * dx;
             g += dy * dy;
             g += dz * dz;
@@ -185,7 +204,7 @@ __device__ __forceinline__ void psi_voxel(const SmoothArgs<S> &a, const SmoothPo
     } else {
         ps = psi_smooth_at(v, p.k, p.j, p.i);  // clamped indices and ghost values
     }
-    a.Ps[p.c0] = (S)ps;
+    a.Ps[(size_t)blockIdx.y * a.vsP + p.c0] = (S)ps;
 }
 
 // sweep: iteration t on hyperplane s = tau - 4t
@@ -194,20 +213,17 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
 {
     const int Z = a.view.Z, Y = a.view.Y, X = a.view.X;
     const int t = p.t, k = p.k, j = p.j, i = p.i;
-    SmoothView<S> v = a.view;
-    S *Dn[3];        // new values (this iteration)
-    const S *Do[3];  // old values (iteration t-1)
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        Dn[c] = pick_buffer(a, t % 3, c);
-        Do[c] = pick_buffer(a, (t + 2) % 3, c);
-        v.Dm1[c] = Do[c];
-        v.Dm2[c] = pick_buffer(a, (t + 1) % 3, c);
-    }
+    SmoothView<S> v = volume_view(a);
+    S *Dn = pick_buffer(a, t % 3);              // new values (this iteration)
+    const S *Do = pick_buffer(a, (t + 2) % 3);  // old values (iteration t-1)
+    v.Dm1 = Do;
+    v.Dm2 = pick_buffer(a, (t + 1) % 3);
+    const S *Ps = a.Ps + (size_t)blockIdx.y * a.vsP;
     const size_t c0 = p.c0;
-    const double d0[3] = {(double)Do[0][c0], (double)Do[1][c0], (double)Do[2][c0]};
-    const double u0[3] = {(double)v.U[0][c0], (double)v.U[1][c0], (double)v.U[2][c0]};
-    const double ps_c = (double)a.Ps[c0];
+    const Rec<S, 3> d0r = ldrec<S, 3>(Do, c0), u0r = ldrec<S, 3>(v.U, c0);
+    const double d0[3] = {(double)d0r.v[0], (double)d0r.v[1], (double)d0r.v[2]};
+    const double u0[3] = {(double)u0r.v[0], (double)u0r.v[1], (double)u0r.v[2]};
+    const double ps_c = (double)Ps[c0];
 
     // neighbours in the reference's order: k-1, k+1, j-1, j+1, i-1, i+1 (:401-471)
     const int nk[6] = {k - 1, k + 1, k, k, k, k};
@@ -226,10 +242,11 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
 #pragma unroll
     for (int q = 0; q < 6; q++) {
         const size_t o = inside[q] ? off[q] : c0;
-        psn[q] = (double)a.Ps[o];
+        psn[q] = (double)Ps[o];
+        const Rec<S, 3> un = ldrec<S, 3>(v.U, o), dn = ldrec<S, 3>(newer[q] ? (const S *)Dn : Do, o);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const double nb = (double)v.U[c][o] + (double)(newer[q] ? Dn[c][o] : Do[c][o]) - u0[c];
+            const double nb = (double)un.v[c] + (double)dn.v[c] - u0[c];
             // ghost: u is edge-padded (u_nb = u_c) and du holds the Neumann copy of the voxel's own
             // previous increment (set_boundary_3d ran right before this sweep)
             term[q][c] = inside[q] ? nb : (u0[c] + d0[c]) - u0[c];
@@ -262,9 +279,10 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
         const int nch = C > 0 ? C : a.C;  // C == 0: channel count at run time (more than 4 channels)
 #pragma unroll
         for (int c = 0; c < nch; c++) {
+            const Rec<S, 12> fr = ldrec<S, 12>(a.A[c] + (size_t)blockIdx.y * a.vsA, c0);
             double f[12];
 #pragma unroll
-            for (int q = 0; q < 12; q++) f[q] = (double)a.A[q * FR3D_MAX_CHANNELS + c][c0];
+            for (int q = 0; q < 12; q++) f[q] = (double)fr.v[q];
             double wt = (double)a.weight[c][c0];
             const double adc = a.a_data[c];
             if (adc != 1.0) {
@@ -287,16 +305,16 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
             bv += wt * (f[1] * f[3] + f[5] * f[7] + f[9] * f[11]);
             bw += wt * (f[2] * f[3] + f[6] * f[7] + f[10] * f[11]);
         }
-        const double vals[9] = {M11, M22, M33, M12, M13, M23, bu, bv, bw};
-#pragma unroll
-        for (int q = 0; q < 9; q++) a.M[q][c0] = (S)vals[q];
+        const Rec<S, 9> mr = {{(S)M11, (S)M22, (S)M33, (S)M12, (S)M13, (S)M23, (S)bu, (S)bv, (S)bw}};
+        strec<S, 9>(a.M + (size_t)blockIdx.y * a.vsM, c0, mr);
         M11 = (double)(S)M11; M22 = (double)(S)M22; M33 = (double)(S)M33;
         M12 = (double)(S)M12; M13 = (double)(S)M13; M23 = (double)(S)M23;
         bu = (double)(S)bu; bv = (double)(S)bv; bw = (double)(S)bw;
     } else {
-        M11 = (double)a.M[0][c0]; M22 = (double)a.M[1][c0]; M33 = (double)a.M[2][c0];
-        M12 = (double)a.M[3][c0]; M13 = (double)a.M[4][c0]; M23 = (double)a.M[5][c0];
-        bu = (double)a.M[6][c0]; bv = (double)a.M[7][c0]; bw = (double)a.M[8][c0];
+        const Rec<S, 9> mr = ldrec<S, 9>(a.M + (size_t)blockIdx.y * a.vsM, c0);
+        M11 = (double)mr.v[0]; M22 = (double)mr.v[1]; M33 = (double)mr.v[2];
+        M12 = (double)mr.v[3]; M13 = (double)mr.v[4]; M23 = (double)mr.v[5];
+        bu = (double)mr.v[6]; bv = (double)mr.v[7]; bw = (double)mr.v[8];
     }
     const double den_u = den + M11, den_v = den + M22, den_w = den + M33;
     double n2 = num[0] - (bu + M12 * d0[1] + M13 * d0[2]);
@@ -305,9 +323,8 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
     const double dv1 = (1.0 - SM_OMEGA) * d0[1] + SM_OMEGA * (den_v != 0.0 ? n2 / den_v : 0.0);
     n2 = num[2] - (bw + M13 * du1 + M23 * dv1);
     const double dw1 = (1.0 - SM_OMEGA) * d0[2] + SM_OMEGA * (den_w != 0.0 ? n2 / den_w : 0.0);
-    Dn[0][c0] = (S)du1;
-    Dn[1][c0] = (S)dv1;
-    Dn[2][c0] = (S)dw1;
+    const Rec<S, 3> out = {{(S)du1, (S)dv1, (S)dw1}};
+    strec<S, 3>(Dn, c0, out);
 }
 
 // One launch per step n, four kinds of workgroups: P-stage tiles (psi_s^t on plane n - 4t, interior
@@ -364,7 +381,7 @@ long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSch
         const StepPart P = part(n), W = part(n - 2);
         const int blocks = P.ntiles + W.ntiles + (P.nt + W.nt) * cb;
         if (blocks <= 0) continue;
-        const dim3 grid(blocks);
+        const dim3 grid(blocks, a.nvol > 0 ? a.nvol : 1);
         switch (a.C) {
             case 1: hipLaunchKernelGGL((k_smooth_step<S, 1>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
             case 2: hipLaunchKernelGGL((k_smooth_step<S, 2>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;

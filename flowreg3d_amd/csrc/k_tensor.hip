@@ -35,19 +35,13 @@ inline TensorScale tensor_scale(double hz, double hy, double hx)
     return t;
 }
 
-// a / b, correctly rounded, from y = RN(1/b): q0 = RN(a*y) is within 2 ulp of a/b, one residual step makes it
-// faithful, and a faithful quotient corrected once more with the exact FMA residual is the correctly rounded one
-// (Markstein's theorem; needs y correctly rounded -- it comes from the host's IEEE division -- and no
-// overflow/underflow, which fp32 image values over grid spacings of order 1 cannot reach).  5 instructions
-// instead of the ~12 of a full fp64 division; 24 of the 27 divisions per voxel divide by a level constant.
-// Differs from a true division only for infinite a (NaN instead of inf) and in the sign of a zero quotient.
+// Division by a level constant as a correctly rounded reciprocal product (div_by_const, fr3d_internal.h): 24 of
+// the 27 divisions per voxel divide by 2h or h^2.
 template <bool UNIT>
 __device__ __forceinline__ double divc(double a, double b, double y)
 {
     if constexpr (UNIT) return a * y;  // y is 0.5 or 1: exact
-    const double q0 = a * y;
-    const double q1 = fma(fma(-b, q0, a), y, q0);
-    return fma(fma(-b, q1, a), y, q1);
+    return div_by_const(a, b, y);
 }
 
 // The 19 samples of one image that the derivatives of one voxel read: centre, 6 face and 12 edge neighbours,
