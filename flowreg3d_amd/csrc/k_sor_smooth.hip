@@ -331,8 +331,14 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
 // voxels), sweep tiles (iteration t on plane n - 2 - 4t, interior voxels), and for each of the two the
 // surface voxels of the same planes packed 256 to a workgroup.  Within a step all four are independent:
 // the sweep reads psi_s of planes finished in earlier steps, the P-stage increments swept in earlier steps.
+// 4 waves per SIMD (128 VGPRs, ~100 B of scratch per lane): 254 ms per 256^3 volume against 274 ms at the
+// 156 VGPRs / 3 waves the compiler picks by itself, 286 ms at 5 waves, 447 ms at 6 (fp32 storage, batch 8)
+#ifndef SM_WPE
+#define SM_WPE 4
+#endif
+#define SM_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SM_WPE, SM_WPE)))
 template <typename S, int C>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) SM_WPE_ATTR
 k_smooth_step(const SmoothArgs<S> a, StepPart P, StepPart W, int cb, const int *__restrict__ meta,
               const int *__restrict__ kj)
 {
