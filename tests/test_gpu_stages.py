@@ -11,7 +11,11 @@ pytestmark = pytest.mark.gpu
 # ---- K1 resample: bit-exact vs oracle (same table code, fp32 sequential accumulation) -----------
 @pytest.mark.parametrize("shape,size", [((18, 22, 26), (11, 15, 17)), ((18, 22, 26), (23, 28, 33)),
                                         ((18, 22, 26), (18, 30, 13)), ((40, 70, 90), (13, 23, 30)),
-                                        ((5, 6, 7), (5, 6, 7)), ((1, 9, 9), (1, 5, 12))])
+                                        ((5, 6, 7), (5, 6, 7)), ((1, 9, 9), (1, 5, 12)),
+                                        # every axis longer: the one-kernel form of the three passes (LDS tiles), several
+                                        # tiles per axis, reflection at both ends, scale 1.25 (pyramid step) up to 22x
+                                        ((41, 52, 105), (52, 65, 131)), ((30, 33, 70), (75, 70, 150)),
+                                        ((9, 9, 9), (40, 41, 200)), ((20, 21, 22), (20, 27, 28))])
 def test_resize_bit_exact_vs_oracle(hip, oracle, shape, size):
     rng = np.random.default_rng(1)
     vol = rng.random(shape, dtype=np.float32)
