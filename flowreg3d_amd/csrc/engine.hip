@@ -1556,7 +1556,6 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     float *Lb = (float *)s.alloc(ns * 3 * 4);
     float *db = (float *)s.alloc(ns * 3 * 4);
     float *dn = (float *)s.alloc(n * 3 * 4);
-    float *Lnat = (float *)s.alloc(n * 3 * 4);
     SorArgs a;
     std::memset(&a, 0, sizeof(a));
     a.sk = sk;
@@ -1580,8 +1579,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     a.iterations = iterations;
     a.update_lag = update_lag;
     if (fast) {
-        launch_laplace<float>(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lnat, Lnat + n, Lnat + 2 * n, true);
-        launch_skew_pack<float, float>(e.st, Lnat, (long long)n, Lb, 3, sk);
+        launch_laplace_rec<float>(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lb);
         launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
     } else {
         float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);

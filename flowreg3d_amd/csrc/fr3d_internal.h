@@ -97,6 +97,23 @@ __device__ __forceinline__ double div_by_const(double a, double b, double y)
     return fma(fma(-b, q1, a), y, q1);
 }
 
+// Anti-diagonal walk of a TY x 32 tile of one z-slice (TY = 32 or 16) by a group of 32 lanes: in step m = 0 .. TY-1
+// lane l handles element (ly, lx).  Lanes with consecutive ly on one diagonal x + y = const are consecutive voxels
+// of a skewed row.  A short diagonal d and its partner d + 32 fill the 32 lanes together (d + 1 and 31 - d
+// elements): every step uses all lanes, where one diagonal per step leaves half of them idle on average.
+template <int TY>
+__device__ __forceinline__ void tile_diag(int lane, int m, int &ly, int &lx)
+{
+    static_assert(TY == 32 || TY == 16, "tile_diag: 32 or 16 rows");
+    if constexpr (TY == 32) {
+        ly = lane;
+        lx = (m - lane) & 31;
+    } else {
+        ly = lane & 15;
+        lx = (m + (lane & 16) - ly) & 31;
+    }
+}
+
 static inline Skew make_skew(int Z, int Y, int X)
 {
     Skew k;
@@ -250,12 +267,6 @@ void launch_motion_tensor_rec(hipStream_t st, const float *f1, const float *f2, 
 
 // K4-K7 SOR
 // narr arrays, src_stride / dst_stride elements apart; element types may differ (converted)
-template <typename TS, typename TD>
-void launch_skew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst,
-                        long long dst_stride, int narr, const Skew &sk);
-template <typename TS, typename TD>
-void launch_unskew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst,
-                          long long dst_stride, int narr, const Skew &sk);
 // nrec (1, 3 or 12) natural planar arrays, src_stride elements apart -> one skewed array of nrec-value records
 // (pitched or compact layout, whatever `sk` describes)
 template <typename TS, typename TD>
@@ -263,10 +274,6 @@ void launch_skew_pack(hipStream_t st, const TS *src, long long src_stride, TD *d
 // skewed records of nrec (3) values -> nrec natural planar arrays, dst_stride elements apart
 template <typename TS, typename TD>
 void launch_unskew_unpack(hipStream_t st, const TS *src, TD *dst, long long dst_stride, int nrec, const Skew &sk);
-// natural = true writes L in the natural (Z,Y,X) layout instead of the skewed one
-template <typename TL>
-void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
-                    double ax, double ay, double az, TL *Lu, TL *Lv, TL *Lw, bool natural = false);
 // the same three terms as one record per voxel in the skewed order of `sk`
 template <typename TL>
 void launch_laplace_rec(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk, double ax,

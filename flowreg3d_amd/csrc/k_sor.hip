@@ -275,98 +275,6 @@ template long long launch_sor<double>(hipStream_t, const SorArgsT<double> &, boo
 
 // ---- layout conversion and the iteration-invariant stencil part -------------------------------
 
-// Natural (Z,Y,X) <-> skewed layout for `narr` arrays at once, through a 64x64 LDS tile of one
-// z-slice: the natural side moves as 256-B row segments (x contiguous), the skewed side as runs
-// along the tile's anti-diagonals (x+y constant => same hyperplane and row, j contiguous), so both
-// sides are coalesced.  A direct scatter costs ~8x write amplification (4-B writes, 128-B lines).
-#define SKT 64
-template <typename TS, typename TD>
-__global__ void __launch_bounds__(256)
-k_skew_tiled(const TS *__restrict__ src, long long src_stride, TD *__restrict__ dst,
-             long long dst_stride, int Z, int Y, int X, int Yp, long long plane, int to_skew)
-{
-    __shared__ TD tile[SKT][SKT + 2];
-    const int txn = (X + SKT - 1) / SKT;
-    const int x0 = (blockIdx.x % txn) * SKT, y0 = (blockIdx.x / txn) * SKT;
-    const int z = blockIdx.y;
-    src += (size_t)blockIdx.z * src_stride;
-    dst += (size_t)blockIdx.z * dst_stride;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // global loads are fetched into registers in groups of 16 before any of them is written to LDS:
-    // a load-then-store loop makes every trip wait for its own load
-    if (to_skew) {
-        TS v[SKT / 4];
-#pragma unroll
-        for (int q = 0; q < SKT / 4; q++) {
-            const int y = y0 + wave + 4 * q, x = x0 + lane;
-            v[q] = (y < Y && x < X) ? src[((size_t)z * Y + y) * X + x] : (TS)0;
-        }
-#pragma unroll
-        for (int q = 0; q < SKT / 4; q++) tile[wave + 4 * q][lane] = (TD)v[q];
-        __syncthreads();
-        for (int d = wave; d < 2 * SKT - 1; d += 4) {
-            const int ly = lane, lx = d - lane;
-            const int y = y0 + ly, x = x0 + lx;
-            if (lx >= 0 && lx < SKT && y < Y && x < X) dst[(size_t)sk_index(X, Yp, plane, z, y, x)] = tile[ly][lx];
-        }
-    } else {
-#pragma unroll
-        for (int g = 0; g < 2; g++) {
-            TS v[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int d = wave + 4 * (16 * g + q);
-                const int ly = lane, lx = d - lane;
-                const int y = y0 + ly, x = x0 + lx;
-                const bool ok = d < 2 * SKT - 1 && lx >= 0 && lx < SKT && y < Y && x < X;
-                v[q] = ok ? src[(size_t)sk_index(X, Yp, plane, z, y, x)] : (TS)0;
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int d = wave + 4 * (16 * g + q);
-                const int lx = d - lane;
-                if (d < 2 * SKT - 1 && lx >= 0 && lx < SKT) tile[lane][lx] = (TD)v[q];
-            }
-        }
-        __syncthreads();
-        for (int row = wave; row < SKT; row += 4) {
-            const int y = y0 + row, x = x0 + lane;
-            if (y < Y && x < X) dst[((size_t)z * Y + y) * X + x] = tile[row][lane];
-        }
-    }
-}
-
-template <typename TS, typename TD>
-static void launch_skew_tiled(hipStream_t st, const TS *src, long long src_stride, TD *dst,
-                              long long dst_stride, int narr, const Skew &sk, int to_skew)
-{
-    if (narr <= 0) return;
-    FR3D_CHECK(sk.Z <= 65535 && narr <= 65535, "skew transposes: z axis longer than 65535");
-    dim3 grid(cdiv(sk.X, SKT) * cdiv(sk.Y, SKT), sk.Z, narr);
-    hipLaunchKernelGGL((k_skew_tiled<TS, TD>), grid, dim3(256), 0, st, src, src_stride, dst, dst_stride, sk.Z,
-                       sk.Y, sk.X, sk.Yp, sk.plane, to_skew);
-    FR3D_LAUNCH_CHECK();
-}
-
-template <typename TS, typename TD>
-void launch_skew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst, long long dst_stride,
-                        int narr, const Skew &sk)
-{
-    launch_skew_tiled<TS, TD>(st, src, src_stride, dst, dst_stride, narr, sk, 1);
-}
-
-template <typename TS, typename TD>
-void launch_unskew_copy_n(hipStream_t st, const TS *src, long long src_stride, TD *dst, long long dst_stride,
-                          int narr, const Skew &sk)
-{
-    launch_skew_tiled<TS, TD>(st, src, src_stride, dst, dst_stride, narr, sk, 0);
-}
-template void launch_skew_copy_n<float, float>(hipStream_t, const float *, long long, float *, long long, int, const Skew &);
-template void launch_skew_copy_n<float, double>(hipStream_t, const float *, long long, double *, long long, int, const Skew &);
-template void launch_skew_copy_n<double, double>(hipStream_t, const double *, long long, double *, long long, int, const Skew &);
-template void launch_unskew_copy_n<float, float>(hipStream_t, const float *, long long, float *, long long, int, const Skew &);
-template void launch_unskew_copy_n<double, float>(hipStream_t, const double *, long long, float *, long long, int, const Skew &);
-
 // NREC natural planar arrays -> one skewed array of NREC-value records (and back), through an LDS tile of
 // TY x 32 voxels of one z-slice: the natural side moves as 128-B row segments, the skewed side as whole records
 // along the tile's anti-diagonals (x+y constant => same hyperplane and row, consecutive j => consecutive
@@ -378,12 +286,12 @@ k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ d
 {
     const int Y = sk.Y, X = sk.X;
     // pitch 34: element (ly, d - ly) of a diagonal sits at 33*ly + d -> consecutive banks for consecutive ly
+    // (tile_diag pairs a short diagonal with the one 32 further on: every step fills its 32 lanes)
     __shared__ TD tile[NREC][TY][PKX + 2];
     const int txn = (X + PKX - 1) / PKX;
     const int x0 = (blockIdx.x % txn) * PKX, y0 = (blockIdx.x / txn) * TY;
     const int z = blockIdx.y;
     const int lane = threadIdx.x % PKX, grp = threadIdx.x / PKX;  // 8 groups of 32
-    constexpr int ND = TY + PKX - 1;                               // anti-diagonals of the tile
     if (to_skew) {
 #pragma unroll
         for (int a = 0; a < NREC; a++) {
@@ -398,20 +306,22 @@ k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ d
                 if (grp + 8 * q < TY) tile[a][grp + 8 * q][lane] = (TD)v[q];
         }
         __syncthreads();
-        for (int d = grp; d < ND; d += 8) {
-            const int ly = lane, lx = d - lane;
+        for (int m = grp; m < TY; m += 8) {
+            int ly, lx;
+            tile_diag<TY>(lane, m, ly, lx);
             const int y = y0 + ly, x = x0 + lx;
-            if (ly < TY && lx >= 0 && lx < PKX && y < Y && x < X) {
+            if (y < Y && x < X) {
                 TD *o = dst + (size_t)sk_index(sk, z, y, x) * NREC;
 #pragma unroll
                 for (int a = 0; a < NREC; a++) o[a] = tile[a][ly][lx];
             }
         }
     } else {
-        for (int d = grp; d < ND; d += 8) {
-            const int ly = lane, lx = d - lane;
+        for (int m = grp; m < TY; m += 8) {
+            int ly, lx;
+            tile_diag<TY>(lane, m, ly, lx);
             const int y = y0 + ly, x = x0 + lx;
-            if (ly < TY && lx >= 0 && lx < PKX && y < Y && x < X) {
+            if (y < Y && x < X) {
                 const TS *o = src + (size_t)sk_index(sk, z, y, x) * NREC;
 #pragma unroll
                 for (int a = 0; a < NREC; a++) tile[a][ly][lx] = (TD)o[a];
@@ -461,37 +371,6 @@ template void launch_unskew_unpack<double, float>(hipStream_t, const double *, f
 
 // L = ax*(u_ip + u_im - 2u) + ay*(...) + az*(...) with edge-padded u (add_boundary,
 // core/optical_flow_3d.py:88), evaluated in fp64 from the fp32-exact level flow.
-template <typename TL>
-__global__ void __launch_bounds__(256)
-k_laplace(const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w,
-          int Z, int Y, int X, int Yp, long long plane, double ax, double ay, double az,
-          TL *__restrict__ Lu, TL *__restrict__ Lv, TL *__restrict__ Lw)
-{
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long total = (long long)Z * Y * X;
-    if (t >= total) return;
-    int x = (int)(t % X);
-    long long r = t / X;
-    int y = (int)(r % Y);
-    int z = (int)(r / Y);
-    const long long sx = 1, sy = X, sz = (long long)Y * X;
-    const long long xm = x > 0 ? -sx : 0, xp = x < X - 1 ? sx : 0;
-    const long long ym = y > 0 ? -sy : 0, yp = y < Y - 1 ? sy : 0;
-    const long long zm = z > 0 ? -sz : 0, zp = z < Z - 1 ? sz : 0;
-    size_t o = plane ? (size_t)sk_index(X, Yp, plane, z, y, x) : (size_t)t;
-    const float *f[3] = {u, v, w};
-    TL *L[3] = {Lu, Lv, Lw};
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        const float *q = f[d] + t;
-        double c = (double)q[0];
-        double acc = ax * ((double)q[xp] + (double)q[xm] - 2.0 * c);
-        acc += ay * ((double)q[yp] + (double)q[ym] - 2.0 * c);
-        acc += az * ((double)q[zp] + (double)q[zm] - 2.0 * c);
-        L[d][o] = (TL)acc;
-    }
-}
-
 // The same three terms written as one record per voxel in the skewed voxel order of `sk` (compact or pitched),
 // through an LDS tile like k_skew_pack / k_motion_tensor_rec.
 template <typename TL>
@@ -526,10 +405,11 @@ k_laplace_rec(const float *__restrict__ u, const float *__restrict__ v, const fl
         }
     }
     __syncthreads();
-    for (int d = grp; d < 32 + PKX - 1; d += 8) {
-        const int ly = lane, lx = d - lane;
+    for (int m = grp; m < 32; m += 8) {
+        int ly, lx;
+        tile_diag<32>(lane, m, ly, lx);
         const int y = y0 + ly, x = x0 + lx;
-        if (lx >= 0 && lx < PKX && y < Y && x < X) {
+        if (y < Y && x < X) {
             TL *o = dst + (size_t)sk_index(sk, z, y, x) * 3;
             o[0] = tile[0][ly][lx];
             o[1] = tile[1][ly][lx];
@@ -551,20 +431,5 @@ template void launch_laplace_rec<float>(hipStream_t, const float *, const float 
                                         double, double, float *);
 template void launch_laplace_rec<double>(hipStream_t, const float *, const float *, const float *, const Skew &, double,
                                          double, double, double *);
-
-template <typename TL>
-void launch_laplace(hipStream_t st, const float *u, const float *v, const float *w, const Skew &sk,
-                    double ax, double ay, double az, TL *Lu, TL *Lv, TL *Lw, bool natural)
-{
-    long long total = (long long)sk.Z * sk.Y * sk.X;
-    hipLaunchKernelGGL(k_laplace<TL>, dim3(cdiv(total, 256)), dim3(256), 0, st, u, v, w, sk.Z, sk.Y,
-                       sk.X, sk.Yp, natural ? 0LL : sk.plane, ax, ay, az, Lu, Lv, Lw);
-    FR3D_LAUNCH_CHECK();
-}
-
-template void launch_laplace<float>(hipStream_t, const float *, const float *, const float *, const Skew &, double,
-                                    double, double, float *, float *, float *, bool);
-template void launch_laplace<double>(hipStream_t, const float *, const float *, const float *, const Skew &, double,
-                                     double, double, double *, double *, double *, bool);
 
 }  // namespace fr3d

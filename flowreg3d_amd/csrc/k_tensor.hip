@@ -210,11 +210,11 @@ k_motion_tensor_rec(Img f1, Img f2, TensorScale hs, TA *__restrict__ dst, const 
         }
     }
     __syncthreads();
-    constexpr int ND = TY + TPX - 1;
-    for (int d = grp; d < ND; d += 8) {
-        const int ly = lane, lx = d - lane;
+    for (int m = grp; m < TY; m += 8) {
+        int ly, lx;
+        tile_diag<TY>(lane, m, ly, lx);
         const int y = y0 + ly, x = x0 + lx;
-        if (ly < TY && lx >= 0 && lx < TPX && y < Y && x < X && !(dbg & 2)) {
+        if (y < Y && x < X && !(dbg & 2)) {
             TA *o = dst + (size_t)sk_index(sk, z, y, x) * 12;
 #pragma unroll
             for (int q = 0; q < 12; q++) o[q] = tile[q][ly][lx];
