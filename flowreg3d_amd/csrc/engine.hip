@@ -488,10 +488,9 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         const float *f1l = rp.f1[li];
 
         // solver operands in the skewed layout, one slab per volume of the batch
-        // a_smooth == 1: compact skewed layout (k_sor.hip); otherwise the a_smooth != 1 kernels (k_sor_smooth.hip)
-        // on the pitched layout.  Both read records and fill the same slabs.
+        // compact skewed layout, records; a_smooth == 1: k_sor.hip, otherwise the psi_smooth kernels (k_sor_smooth.hip)
         const bool fast = p.a_smooth == 1.0;
-        const Skew sk = fast ? e.compact_skew(lz, ly, lx) : make_skew(lz, ly, lx);
+        const Skew sk = e.compact_skew(lz, ly, lx);
         const size_t ns = (size_t)sk.total;
         const size_t nres = (size_t)std::max(nb, reserve_nb);  // slabs reserved (>= nb)
         S *Mbuf = (S *)e.bufs["M_sk" + sn].ensure(ns * 9 * nres * sizeof(S));
@@ -590,7 +589,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
             S *smP = (S *)e.bufs["sm_P" + sn].ensure(ns * nb * sizeof(S));
             SmoothArgs<S> sa;
             std::memset(&sa, 0, sizeof(sa));
-            sa.view.Z = lz; sa.view.Y = ly; sa.view.X = lx; sa.view.Yp = sk.Yp; sa.view.plane = sk.plane;
+            sa.view.Z = lz; sa.view.Y = ly; sa.view.X = lx; sa.view.sk = sk;
             smooth_set_spacing(sa.view, hx, hy, hz);
             sa.view.a_smooth = p.a_smooth;
             sa.view.U = smU;
@@ -706,7 +705,7 @@ static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std:
 // How many volumes to solve in lock step: FR3D_BATCH (default 4), bounded by free HBM
 // (29 skewed operand arrays per volume and channel set).
 static int g_batch_hint = 0;  // fr3d_set_batch()
-static bool g_fast_path = true;  // a_smooth == 1 of the call in progress (compact solver slabs)
+static bool g_fast_path = true;  // a_smooth == 1 of the call in progress (the psi_smooth path holds 13 more values per voxel)
 static bool g_fp64_storage = false;
 
 // fr3d_set_batch(), else FR3D_BATCH, else 4
@@ -723,7 +722,7 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
     if (want < 1) want = 1;
     const Level &F = lv.back();
     Skew sk = make_skew(F.z, F.y, F.x);
-    if (g_fast_path) {  // packed rows: 1.1-1.3x the voxel count instead of 3x
+    {   // packed rows: 1.1-1.3x the voxel count
         std::vector<long long> pb;
         std::vector<int> cp;
         sk.total = make_compact_tables(F.z, F.y, F.x, pb, cp);
@@ -1543,8 +1542,8 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     FR3D_CHECK(iterations >= 0 && update_lag >= 1, "iterations >= 0 and update_lag >= 1 required");
     Engine &e = g_eng;
     const size_t n = (size_t)Z * Y * X;
-    const bool fast = a_smooth == 1.0;  // compact layout (k_sor.hip) / pitched layout (k_sor_smooth.hip); records in both
-    const Skew sk = fast ? e.compact_skew(Z, Y, X) : make_skew(Z, Y, X);
+    const bool fast = a_smooth == 1.0;  // k_sor.hip / k_sor_smooth.hip; compact layout and records in both
+    const Skew sk = e.compact_skew(Z, Y, X);
     const size_t ns = (size_t)sk.total;
     Staged s;
     const float *dA = (const float *)s.up(A, n * 12 * C * 4);
@@ -1585,7 +1584,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
         float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);
         SmoothArgs<float> sa;
         std::memset(&sa, 0, sizeof(sa));
-        sa.view.Z = Z; sa.view.Y = Y; sa.view.X = X; sa.view.Yp = sk.Yp; sa.view.plane = sk.plane;
+        sa.view.Z = Z; sa.view.Y = Y; sa.view.X = X; sa.view.sk = sk;
         smooth_set_spacing(sa.view, hx, hy, hz);
         sa.view.a_smooth = a_smooth;
         launch_skew_pack<float, float>(e.st, dU, (long long)n, smU, 3, sk);

@@ -192,13 +192,13 @@ struct SmoothView {
     const S *U;    // u,v,w skewed (interior), records of 3
     const S *Dm1;  // increments of iteration t-1, records of 3
     const S *Dm2;  // increments of iteration t-2 (ghost source)
-    int Z, Y, X, Yp;
-    long long plane;
+    int Z, Y, X;
+    Skew sk;       // storage of the skewed rows (compact or pitched)
     double tx, ty, tz, rtx, rty, rtz;  // 2h per axis and RN(1 / 2h) (div_by_const)
     double a_smooth;
 };
 
-// Pitched skewed layout; every per-volume operand of a lock-step batch is `vs*` elements behind the previous
+// Every per-volume operand of a lock-step batch is `vs*` elements behind the previous
 // volume's (the kernel's blockIdx.y is the volume of the batch); `weight` is shared.
 template <typename S>
 struct SmoothArgs {

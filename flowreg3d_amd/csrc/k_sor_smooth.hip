@@ -19,7 +19,7 @@
 //    fp64 arithmetic (the (u + du) - u differences cancel in fp32); not on any BASELINE configuration
 //    (OFOptions.a_smooth = 1.0), but get_displacement's own default.
 //  * operands are records like in k_sor.hip (u,v,w / du,dv,dw: 3 values, system: 9, factors: 12 per voxel
-//    contiguous, pitched skewed rows), so a neighbour costs three wide loads instead of seven dword loads, and
+//    contiguous, compact skewed rows), so a neighbour costs three wide loads instead of seven dword loads, and
 //    the volumes of a lock-step batch share the launches (blockIdx.y = volume of the batch).
 #include <cstdlib>
 
@@ -38,7 +38,7 @@ __device__ __forceinline__ void uu3_at(const SmoothView<S> &v, int k, int j, int
     const int kc = k < 0 ? 0 : (k >= v.Z ? v.Z - 1 : k);
     const int jc = j < 0 ? 0 : (j >= v.Y ? v.Y - 1 : j);
     const int ic = i < 0 ? 0 : (i >= v.X ? v.X - 1 : i);
-    const long long o = sk_index(v.X, v.Yp, v.plane, kc, jc, ic);
+    const long long o = sk_index(v.sk, kc, jc, ic);
     // both buffers are read and the value is selected: selecting the POINTER (v.Dm2 vs v.Dm1) would cost a
     // 64-bit select per access and no load less
     const Rec<S, 3> u = ldrec<S, 3>(v.U, o), d1 = ldrec<S, 3>(v.Dm1, o), d2 = ldrec<S, 3>(v.Dm2, o);
@@ -107,8 +107,8 @@ struct SmoothPos {
 template <typename S>
 __device__ __forceinline__ bool smooth_offsets(const SmoothArgs<S> &a, int s, int k, int jj_or_j, bool is_jj, SmoothPos &p)
 {
-    const int Z = a.view.Z, Y = a.view.Y, X = a.view.X, Yp = a.view.Yp;
-    const long long plane = a.view.plane;
+    const int Z = a.view.Z, Y = a.view.Y, X = a.view.X;
+    const Skew &sk = a.view.sk;
     if (k >= Z) return false;
     const int r = s - k;
     const int jm0 = sk_jm(X, r);
@@ -118,15 +118,25 @@ __device__ __forceinline__ bool smooth_offsets(const SmoothArgs<S> &a, int s, in
     p.j = jj + jm0;
     p.i = r - p.j;
     if (r < 0 || p.j >= Y || p.i < 0) return false;
-    const long long c0 = (long long)s * plane + (long long)k * Yp + jj;
+    // row starts: own, (s-1,k), (s-1,k-1), (s+1,k), (s+1,k+1) -- compact rows (pb/cp tables, see Skew and
+    // k_sor_step) or pitched rows; the rows k-1 / k+1 of the neighbouring planes have the same i+j as this row
+    long long b0, bm, bzm, bp, bzp;
+    if (sk.pb) {
+        const long long pm = sk.pb[s], p0 = sk.pb[s + 1], pp = sk.pb[s + 2];
+        const long long cm = sk.cp[r], c_ = sk.cp[r + 1], cpn = sk.cp[r + 2];
+        b0 = p0 - c_; bm = pm - cm; bzm = pm - c_; bp = pp - cpn; bzp = pp - c_;
+    } else {
+        b0 = (long long)s * sk.plane + (long long)k * sk.Yp;
+        bm = b0 - sk.plane; bzm = bm - sk.Yp; bp = b0 + sk.plane; bzp = bp + sk.Yp;
+    }
     const long long d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
-    p.c0 = (size_t)c0;
-    p.xm = (size_t)(c0 - plane + d1);
-    p.xp = (size_t)(c0 + plane + d2);
-    p.ym = (size_t)(c0 - plane + d1 - 1);
-    p.yp = (size_t)(c0 + plane + d2 + 1);
-    p.zm = (size_t)(c0 - plane - Yp);
-    p.zp = (size_t)(c0 + plane + Yp);
+    p.c0 = (size_t)(b0 + jj);
+    p.xm = (size_t)(bm + jj + d1);
+    p.xp = (size_t)(bp + jj + d2);
+    p.ym = (size_t)(bm + jj + d1 - 1);
+    p.yp = (size_t)(bp + jj + d2 + 1);
+    p.zm = (size_t)(bzm + jj);
+    p.zp = (size_t)(bzp + jj);
     return true;
 }
 template <typename S>
@@ -152,7 +162,8 @@ __device__ __forceinline__ bool locate_tile(const SmoothArgs<S> &a, int b, const
     const SorEntry en = P.ent[lo];
     const int local = b - en.pre;
     p.t = P.t_lo + lo;
-    const int k = (en.kb0 + local / en.njb) * (int)blockDim.y + threadIdx.y;
+    // a wave is one row (blockDim.x == 64): its row number is wave-uniform, which keeps the row starts in SGPRs
+    const int k = (en.kb0 + local / en.njb) * (int)blockDim.y + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
     const int jj = (local % en.njb) * 64 + threadIdx.x;
     if (!smooth_offsets(a, P.tau - SM_LAG * p.t, k, jj, true, p)) return false;
     return !on_surface(a, p);
@@ -331,8 +342,9 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
 // voxels), sweep tiles (iteration t on plane n - 2 - 4t, interior voxels), and for each of the two the
 // surface voxels of the same planes packed 256 to a workgroup.  Within a step all four are independent:
 // the sweep reads psi_s of planes finished in earlier steps, the P-stage increments swept in earlier steps.
-// 4 waves per SIMD (128 VGPRs, ~100 B of scratch per lane): 254 ms per 256^3 volume against 274 ms at the
-// 156 VGPRs / 3 waves the compiler picks by itself, 286 ms at 5 waves, 447 ms at 6 (fp32 storage, batch 8)
+// 4 waves per SIMD (128 VGPRs, ~150 B of scratch per lane): 273 ms per 256^3 volume against 297 ms at the
+// 159 VGPRs / 3 waves the compiler picks by itself (fp32 storage, batch 8; on pitched rows the same kernel
+// measured 254 / 274 ms, 286 ms at 5 waves and 447 ms at 6 -- the compact rows cost 7 % here and save 2.4x memory)
 #ifndef SM_WPE
 #define SM_WPE 4
 #endif
