@@ -143,6 +143,11 @@ def fullsize_case(name):
     if name == "cfg2":
         fixed, moving, gt = fast_pair((256, 256, 256))
         return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=4)
+    if name == "cfg2_asmooth05":
+        # config 2's volume and pyramid with get_displacement's own default a_smooth = 0.5 (the psi_smooth
+        # solver path; no BASELINE configuration uses it)
+        fixed, moving, gt = fast_pair((256, 256, 256))
+        return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=4, a_smooth=0.5)
     if name == "cfg3":
         fixed, moving, gt = fast_pair((512, 512, 512))
         return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=5)

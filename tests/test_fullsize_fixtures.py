@@ -10,7 +10,7 @@ import pytest
 
 from conftest import GOLDEN
 
-CASES = [c for c in ("cfg2", "cfg3", "cfg5") if os.path.exists(os.path.join(GOLDEN, f"fullsize_{c}.npz"))]
+CASES = [c for c in ("cfg2", "cfg2_asmooth05", "cfg3", "cfg5") if os.path.exists(os.path.join(GOLDEN, f"fullsize_{c}.npz"))]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -29,8 +29,10 @@ def test_fixture_is_well_formed(case):
     assert meta["epe_oracle_vs_gt_mean_interior8"] < 1.0
 
 
-def test_all_three_cases_are_committed():
-    assert CASES == ["cfg2", "cfg3", "cfg5"]
+def test_all_cases_are_committed():
+    assert CASES == ["cfg2", "cfg2_asmooth05", "cfg3", "cfg5"]
+    meta = json.loads(bytes(np.load(os.path.join(GOLDEN, "fullsize_cfg2_asmooth05.npz"))["meta"]).decode())
+    assert meta["params"]["a_smooth"] == 0.5 and meta["params"]["levels"] == 4
 
 
 def test_cfg2_inputs_reproduce():

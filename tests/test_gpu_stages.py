@@ -145,6 +145,21 @@ def test_motion_tensor_vs_reference_golden(hip):
         assert np.array_equal(J[a], want.astype(np.float32).astype(np.float64))
 
 
+@pytest.mark.parametrize("h", [(1.0, 1.0, 1.0), (1.25, 1.25, 1.25), (256 / 205, 256 / 164, 512 / 210), (3.7, 0.9, 11.0)])
+def test_motion_tensor_bit_exact_vs_oracle_spacings(hip, oracle, h):
+    """The kernel divides by the level constants 2h and h^2 through a reciprocal product with two residual
+    corrections (div_by_const): it must round like the true division for any spacing, including the exact
+    x0.5 / x1 shortcut of the full-resolution level."""
+    from flowreg3d_amd.synthetic import make_pair
+    f1, f2, _ = make_pair((14, 23, 37), seed=21, scale=0.4)
+    f1[2, 3, 4] = f2[2, 3, 4] = 0.0
+    f1[:, :2] = 0.0                      # flat regions: zero numerators
+    J = hip.get_motion_tensor_gc(f1, f2, *h)
+    want = oracle.get_motion_tensor_gc(f1, f2, *h)
+    for a in range(10):
+        assert np.array_equal(J[a], np.asarray(want[a]).astype(np.float32).astype(np.float64)), a
+
+
 # ---- K4-K7 solver -------------------------------------------------------------------------------------
 def _solve(hip, g, J, wt, it, lag, ad, fp64):
     hx, hy, hz = g["h"]

@@ -6,7 +6,7 @@ flow field plus a checksum of the inputs under tests/golden/.  tests/test_gpu_fu
 regenerates the same inputs on the GPU box, verifies the checksum, runs the HIP path in its
 default (benched) solver mode at the full 100 iterations and compares on the sample.
 
-  python tools/gen_fullsize_golden.py cfg2|cfg3|cfg5 [--out tests/golden]
+  python tools/gen_fullsize_golden.py cfg2|cfg2_asmooth05|cfg3|cfg5 [--out tests/golden]
 
 Cost on one core of the build container: cfg2 (256^3) ~4 min / 3 GB, cfg5 (256x512x512, C=2)
 ~20 min / 25 GB, cfg3 (512^3) ~30 min / 22 GB.
@@ -44,7 +44,7 @@ def sample(flow, stride, block):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("case", choices=("cfg2", "cfg3", "cfg5"))
+    ap.add_argument("case", choices=("cfg2", "cfg2_asmooth05", "cfg3", "cfg5"))
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--stride", type=int, default=8)
     ap.add_argument("--block", type=int, default=32)
