@@ -662,16 +662,14 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
     const size_t nl = (size_t)pz * py * px;
     for (int b = 0; b < nb; b++) {
         float **u = &uvw[3 * b];
-        float *full = e.f32("d_nat", nfull * 3);  // the increments' scratch is free after the last level
         if (min_level > 0) {
+            float *full = e.f32("d_nat", nfull * 3);  // the increments' scratch is free after the last level
             for (int d = 0; d < 3; d++) resize3d(e, u[d], 1, 0, pz, py, px, Z, Y, X, full + (size_t)d * nfull);
+            launch_pack3(e.st, full, full + nfull, full + 2 * nfull, (long long)nfull, flow_out[b]);
         } else {
             FR3D_CHECK(nl == nfull, "internal: finest level is not full resolution");
-            for (int d = 0; d < 3; d++)
-                FR3D_HIP(hipMemcpyAsync(full + (size_t)d * nfull, u[d], nfull * sizeof(float),
-                                        hipMemcpyDeviceToDevice, e.st));
+            launch_pack3(e.st, u[0], u[1], u[2], (long long)nfull, flow_out[b]);
         }
-        launch_pack(e.st, full, 3, (long long)nfull, flow_out[b]);
     }
 }
 

@@ -346,6 +346,7 @@ void launch_fill(hipStream_t st, float *y, float v, long long n);
 void launch_read8(hipStream_t st, const float *x, long long n, float *sink);
 // interleave/deinterleave between (n,C) channels-last and planar (C,n)
 void launch_pack(hipStream_t st, const float *planar, int C, long long n, float *interleaved);
+void launch_pack3(hipStream_t st, const float *a, const float *b, const float *c, long long n, float *interleaved);
 void launch_unpack(hipStream_t st, const float *interleaved, int C, long long n, float *planar);
 
 }  // namespace fr3d

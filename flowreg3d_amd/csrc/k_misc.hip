@@ -105,6 +105,25 @@ void launch_fill(hipStream_t st, float *y, float v, long long n)
     if (n > 0) hipLaunchKernelGGL(k_fill, dim3(cdiv(n, 256)), dim3(256), 0, st, y, v, n);
     FR3D_LAUNCH_CHECK();
 }
+// three separate component arrays -> (n, 3) interleaved; one voxel per thread (a wave reads three 256-B runs and
+// writes one 768-B run)
+__global__ void __launch_bounds__(256)
+k_pack3(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c, long long n,
+        float *__restrict__ inter)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float x = a[t], y = b[t], z = c[t];
+    float *o = inter + t * 3;
+    o[0] = x;
+    o[1] = y;
+    o[2] = z;
+}
+void launch_pack3(hipStream_t st, const float *a, const float *b, const float *c, long long n, float *inter)
+{
+    if (n > 0) hipLaunchKernelGGL(k_pack3, dim3(cdiv(n, 256)), dim3(256), 0, st, a, b, c, n, inter);
+    FR3D_LAUNCH_CHECK();
+}
 void launch_pack(hipStream_t st, const float *planar, int C, long long n, float *inter)
 {
     if (n > 0) hipLaunchKernelGGL(k_pack, dim3(cdiv(n * C, 256)), dim3(256), 0, st, planar, C, n, inter);
