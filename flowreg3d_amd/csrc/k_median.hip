@@ -337,12 +337,16 @@ struct MedianDst {
     int acc;
 };
 
+// mirror() for an index at most 2 outside [0, n) of an axis with n >= 3: no modulo (the general form costs an
+// emulated integer division per call, ~20 instructions, a dozen times per lane)
+__device__ __forceinline__ int mirror2(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
 __device__ __forceinline__ void median_offsets(int z, int y, int Z, int Y, int X, unsigned (&zo)[5], unsigned (&yo)[5])
 {
 #pragma unroll
     for (int q = 0; q < 5; q++) {
-        zo[q] = (unsigned)mirror(z + q - 2, Z) * (unsigned)Y * (unsigned)X;
-        yo[q] = (unsigned)mirror(y + q - 2, Y) * (unsigned)X;
+        zo[q] = (unsigned)mirror2(z + q - 2, Z) * (unsigned)Y * (unsigned)X;
+        yo[q] = (unsigned)mirror2(y + q - 2, Y) * (unsigned)X;
     }
 }
 
@@ -374,7 +378,7 @@ k_median5_flat(const float *__restrict__ in, long long fstride, int Z, int Y, in
         unsigned zo[5], yo[5];
         median_offsets(z, y, Z, Y, X, zo, yo);
         sort_store(zo, yo, 2 * xp, 0, L + 1);
-        sort_store(zo, yo, mirror(2 * xp + 1, X), 1, L + 1);
+        sort_store(zo, yo, mirror2(2 * xp + 1, X), 1, L + 1);
     }
     // the columns outside the workgroup: x0-2, x0-1 of its first lane and x0+2, x0+3 of its last one.  One
     // more sorting pass of one wave (a pass costs the same for 4 active lanes as for 64); the wave rotates
@@ -388,7 +392,7 @@ k_median5_flat(const float *__restrict__ in, long long fstride, int Z, int Y, in
             unsigned zo[5], yo[5];
             median_offsets((int)(r / (unsigned)Y), (int)(r % (unsigned)Y), Z, Y, X, zo, yo);
             const int col = 2 * hxp + (h == 0 ? -2 : h == 1 ? -1 : h == 2 ? 2 : 3);
-            sort_store(zo, yo, mirror(col, X), h & 1, h < 2 ? 0 : MF_W - 1);
+            sort_store(zo, yo, mirror2(col, X), h & 1, h < 2 ? 0 : MF_W - 1);
         }
     }
     __syncthreads();
@@ -439,7 +443,7 @@ void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float 
 static bool median_flat_ok(int Z, int Y, int X, int nf)
 {
     const long long n = (long long)Z * Y * X;
-    return X >= 8 && n < (1ll << 32) && nf >= 1 && nf <= 3;
+    return X >= 8 && Y >= 3 && Z >= 3 && n < (1ll << 32) && nf >= 1 && nf <= 3;
 }
 
 bool median_can_accumulate(int Z, int Y, int X)
