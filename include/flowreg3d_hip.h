@@ -70,7 +70,7 @@ const char *fr3d_version(void);
  * GiB") for logs and bench output; "" before fr3d_init. */
 const char *fr3d_device_info(void);
 /* Volumes of a batch that fr3d_process_batch solves in lock step (their SOR launches are shared;
- * default 4, env FR3D_BATCH).  Also reserves solver workspace for that many volumes on first use,
+ * default 8, env FR3D_BATCH).  Also reserves solver workspace for that many volumes on first use,
  * so a later full batch does not reallocate.  0 restores the default. */
 int fr3d_set_batch(int nvol);
 
