@@ -5,6 +5,8 @@
 // the file is compiled with -ffp-contract=off) so the result is bit-identical to the CPU path.
 // HBM-bound streaming: threads run along the innermost output axis (coalesced stores; the P taps
 // of neighbouring outputs overlap, so the gathers are served by L1/L2).
+#include <cstdlib>
+
 #include "fr3d_internal.h"
 
 namespace fr3d {
@@ -73,6 +75,42 @@ k_resize_x(const float *__restrict__ src, int cs, int co, long long rows, int n2
     }
 }
 
+// axis 2 on a planar source with rows of at most RXL_MAXN samples: a workgroup stages RXL_ROWS whole rows in LDS
+// with one contiguous, fully coalesced read (consecutive rows are adjacent in memory) and gathers the taps there.
+// The register form above keeps 2*PT dependent gathers per thread in flight and waits for them four times per
+// workgroup; here every global load of the workgroup is issued at once.  Same sums in the same order.
+#define RXL_ROWS 8
+#define RXL_MAXN 1024
+template <int PT>
+__global__ void __launch_bounds__(256)
+k_resize_x_lds(const float *__restrict__ src, long long rows, int n2, int out_len, const int *__restrict__ idx,
+               const float *__restrict__ wt, float *__restrict__ dst)
+{
+    extern __shared__ float rowbuf[];  // RXL_ROWS x n2
+    const long long row0 = (long long)blockIdx.x * RXL_ROWS;
+    const int nr = (int)(rows - row0 < RXL_ROWS ? rows - row0 : RXL_ROWS);
+    const long long total = (long long)nr * n2;
+    const float *__restrict__ base = src + (size_t)row0 * n2;
+    for (long long e = threadIdx.x; e < total; e += 256) rowbuf[e] = base[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < out_len; i += 256) {
+        int tap[PT];
+        float w[PT];
+#pragma unroll
+        for (int p = 0; p < PT; p++) {
+            tap[p] = idx[(size_t)i * PT + p];
+            w[p] = wt[(size_t)i * PT + p];
+        }
+        for (int r = 0; r < nr; r++) {
+            const float *row = rowbuf + r * n2;
+            float a = 0.0f;
+#pragma unroll
+            for (int p = 0; p < PT; p++) a += row[tap[p]] * w[p];  // tap order and fp32 mul/add as the reference
+            dst[(size_t)(row0 + r) * out_len + i] = a;
+        }
+    }
+}
+
 // axis 1 or 0 on planar data: src viewed as (outer, n, inner), dst (outer, out_len, inner).
 // blockIdx.y = output index along the axis, blockIdx.z = outer: the P taps and weights of a
 // workgroup are wave-uniform (scalar loads), the P gathers are independent coalesced row reads.
@@ -129,6 +167,21 @@ void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0
         long long total = rows * out_len;
         if (total == 0) return;
         (void)total;
+        static const char *xl_env = getenv("FR3D_RESIZE_XLDS");  // A/B aid: 0 = register form only
+        if (cs == 1 && co == 0 && n2 <= RXL_MAXN && P >= 1 && P <= RX_MAXP && !(xl_env && xl_env[0] == '0')) {
+            const dim3 grid((unsigned)cdiv(rows, RXL_ROWS));
+            const size_t lds = (size_t)RXL_ROWS * n2 * sizeof(float);
+#define FR3D_RXL(PT) hipLaunchKernelGGL((k_resize_x_lds<PT>), grid, dim3(256), lds, st, src, rows, n2, out_len, idx, wt, dst)
+            switch (P) {
+                case 1: FR3D_RXL(1); break;   case 2: FR3D_RXL(2); break;   case 3: FR3D_RXL(3); break;   case 4: FR3D_RXL(4); break;
+                case 5: FR3D_RXL(5); break;   case 6: FR3D_RXL(6); break;   case 7: FR3D_RXL(7); break;   case 8: FR3D_RXL(8); break;
+                case 9: FR3D_RXL(9); break;   case 10: FR3D_RXL(10); break; case 11: FR3D_RXL(11); break; case 12: FR3D_RXL(12); break;
+                case 13: FR3D_RXL(13); break; case 14: FR3D_RXL(14); break; case 15: FR3D_RXL(15); break; default: FR3D_RXL(16); break;
+            }
+#undef FR3D_RXL
+            FR3D_LAUNCH_CHECK();
+            return;
+        }
         int rpb = RX_ROWS;
         if (cdiv(rows, rpb) > 65535) rpb = cdiv(rows, 65535);
         dim3 grid(cdiv(out_len, 256), cdiv(rows, rpb));
