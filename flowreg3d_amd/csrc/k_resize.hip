@@ -122,19 +122,33 @@ k_resize_mid(const float *__restrict__ src, int n, long long inner, int out_len,
 {
     const long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= inner) return;
-    const int i = blockIdx.y;
     const long long o = blockIdx.z;
     const float *base = src + (size_t)o * n * inner + x;
-    const int *ii = idx + (size_t)i * P;
-    const float *ww = wt + (size_t)i * P;
-    float a = 0.0f;
     if constexpr (PT > 0) {
-        float v[PT];
+        // two outputs along the axis per thread: 2*PT independent row reads in flight (neighbouring outputs share
+        // most of their taps, the second read of a row is an L1 hit)
+        const int i0 = 2 * blockIdx.y, i1 = i0 + 1 < out_len ? i0 + 1 : i0;
+        const int *ii0 = idx + (size_t)i0 * PT, *ii1 = idx + (size_t)i1 * PT;
+        const float *w0 = wt + (size_t)i0 * PT, *w1 = wt + (size_t)i1 * PT;
+        float v0[PT], v1[PT];
 #pragma unroll
-        for (int p = 0; p < PT; p++) v[p] = base[(size_t)ii[p] * inner];
+        for (int p = 0; p < PT; p++) {
+            v0[p] = base[(size_t)ii0[p] * inner];
+            v1[p] = base[(size_t)ii1[p] * inner];
+        }
+        float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-        for (int p = 0; p < PT; p++) a += v[p] * ww[p];  // tap order as the reference
+        for (int p = 0; p < PT; p++) {  // tap order as the reference
+            a0 += v0[p] * w0[p];
+            a1 += v1[p] * w1[p];
+        }
+        dst[((size_t)o * out_len + i0) * inner + x] = a0;
+        if (i1 != i0) dst[((size_t)o * out_len + i1) * inner + x] = a1;
     } else {
+        const int i = blockIdx.y;
+        const int *ii = idx + (size_t)i * P;
+        const float *ww = wt + (size_t)i * P;
+        float a = 0.0f;
         // taps in groups of 8: the gathers of a group are independent and leave together, the sum keeps
         // the reference's tap order (a one-tap-per-trip loop waits for every load in turn)
         for (int p0 = 0; p0 < P; p0 += 8) {
@@ -145,8 +159,8 @@ k_resize_mid(const float *__restrict__ src, int n, long long inner, int out_len,
             for (int q = 0; q < 8; q++)
                 if (p0 + q < P) a += v[q] * ww[p0 + q];
         }
+        dst[((size_t)o * out_len + i) * inner + x] = a;
     }
-    dst[((size_t)o * out_len + i) * inner + x] = a;
 }
 
 // dispatch on the tap count: 1..16 as template constants, anything longer through the generic loop
@@ -197,7 +211,8 @@ void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0
         if (total == 0) return;
         FR3D_CHECK(out_len <= 65535 && outer <= 65535, "resize: axis length beyond the grid limits");
         const int bx = inner >= 256 ? 256 : cdiv(inner, 64) * 64;  // short rows: no idle waves
-        const dim3 grid(cdiv(inner, bx), out_len, (unsigned)outer);
+        // template tap counts (1..16): two outputs along the axis per thread; generic form: one
+        const dim3 grid(cdiv(inner, bx), (P >= 1 && P <= RX_MAXP) ? cdiv(out_len, 2) : out_len, (unsigned)outer);
 #define FR3D_RM(PT) hipLaunchKernelGGL((k_resize_mid<PT>), grid, dim3(bx), 0, st, src, n, inner, out_len, idx, wt, P, dst)
         FR3D_TAP_SWITCH(P, FR3D_RM)
 #undef FR3D_RM
