@@ -114,6 +114,9 @@ k_resize_x_lds(const float *__restrict__ src, long long rows, int n2, int out_le
 // axis 1 or 0 on planar data: src viewed as (outer, n, inner), dst (outer, out_len, inner).
 // blockIdx.y = output index along the axis, blockIdx.z = outer: the P taps and weights of a
 // workgroup are wave-uniform (scalar loads), the P gathers are independent coalesced row reads.
+#ifndef RM_NOUT
+#define RM_NOUT 4
+#endif
 template <int PT>
 __global__ void __launch_bounds__(256)
 k_resize_mid(const float *__restrict__ src, int n, long long inner, int out_len,
@@ -125,25 +128,24 @@ k_resize_mid(const float *__restrict__ src, int n, long long inner, int out_len,
     const long long o = blockIdx.z;
     const float *base = src + (size_t)o * n * inner + x;
     if constexpr (PT > 0) {
-        // two outputs along the axis per thread: 2*PT independent row reads in flight (neighbouring outputs share
-        // most of their taps, the second read of a row is an L1 hit)
-        const int i0 = 2 * blockIdx.y, i1 = i0 + 1 < out_len ? i0 + 1 : i0;
-        const int *ii0 = idx + (size_t)i0 * PT, *ii1 = idx + (size_t)i1 * PT;
-        const float *w0 = wt + (size_t)i0 * PT, *w1 = wt + (size_t)i1 * PT;
-        float v0[PT], v1[PT];
+        // RM_NOUT outputs along the axis per thread: RM_NOUT*PT independent row reads in flight (neighbouring outputs
+        // share most of their taps, the repeated read of a row is an L1 hit)
+        float v[RM_NOUT][PT];
 #pragma unroll
-        for (int p = 0; p < PT; p++) {
-            v0[p] = base[(size_t)ii0[p] * inner];
-            v1[p] = base[(size_t)ii1[p] * inner];
-        }
-        float a0 = 0.0f, a1 = 0.0f;
+        for (int q = 0; q < RM_NOUT; q++) {
+            const int i = min(RM_NOUT * (int)blockIdx.y + q, out_len - 1);
 #pragma unroll
-        for (int p = 0; p < PT; p++) {  // tap order as the reference
-            a0 += v0[p] * w0[p];
-            a1 += v1[p] * w1[p];
+            for (int p = 0; p < PT; p++) v[q][p] = base[(size_t)idx[(size_t)i * PT + p] * inner];
         }
-        dst[((size_t)o * out_len + i0) * inner + x] = a0;
-        if (i1 != i0) dst[((size_t)o * out_len + i1) * inner + x] = a1;
+#pragma unroll
+        for (int q = 0; q < RM_NOUT; q++) {
+            const int i = RM_NOUT * (int)blockIdx.y + q;
+            if (i >= out_len) break;
+            float a = 0.0f;
+#pragma unroll
+            for (int p = 0; p < PT; p++) a += v[q][p] * wt[(size_t)i * PT + p];  // tap order as the reference
+            dst[((size_t)o * out_len + i) * inner + x] = a;
+        }
     } else {
         const int i = blockIdx.y;
         const int *ii = idx + (size_t)i * P;
@@ -211,8 +213,8 @@ void launch_resize_pass(hipStream_t st, const float *src, int cs, int co, int n0
         if (total == 0) return;
         FR3D_CHECK(out_len <= 65535 && outer <= 65535, "resize: axis length beyond the grid limits");
         const int bx = inner >= 256 ? 256 : cdiv(inner, 64) * 64;  // short rows: no idle waves
-        // template tap counts (1..16): two outputs along the axis per thread; generic form: one
-        const dim3 grid(cdiv(inner, bx), (P >= 1 && P <= RX_MAXP) ? cdiv(out_len, 2) : out_len, (unsigned)outer);
+        // template tap counts (1..16): RM_NOUT outputs along the axis per thread; generic form: one
+        const dim3 grid(cdiv(inner, bx), (P >= 1 && P <= RX_MAXP) ? cdiv(out_len, RM_NOUT) : out_len, (unsigned)outer);
 #define FR3D_RM(PT) hipLaunchKernelGGL((k_resize_mid<PT>), grid, dim3(bx), 0, st, src, n, inner, out_len, idx, wt, P, dst)
         FR3D_TAP_SWITCH(P, FR3D_RM)
 #undef FR3D_RM
