@@ -45,6 +45,9 @@ for _ in range(3):
 import hashlib, numpy as np
 out = np.empty((n, n, n, 3), np.float32); lib.fr3d_d2h(out.ctypes.data, flows, nv * 12)
 best["flow_sha"] = hashlib.sha256(out.tobytes()).hexdigest()[:12]
+st = C.c_double(0.0)
+lib.fr3d_stream_probe(1 << 28, 10, C.byref(st))
+best["stream_GBs"] = round(st.value)  # ~5300: the box state in which the 256^3 sweep runs at 0.51; ~5700: 0.48
 print(json.dumps(best))
 """ % ROOT
 
