@@ -93,6 +93,8 @@ SIGNATURES = {
                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _vp]),
     "fr3d_median5": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _ip, C.c_int, _ip]),
+    "fr3d_sor_schedule_check": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.POINTER(C.c_longlong)]),
     "fr3d_dev_malloc": (C.c_void_p, [C.c_size_t]),
     "fr3d_dev_free": (None, [_vp]),
     "fr3d_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
@@ -212,7 +214,7 @@ def make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth,
     for c in range(n_channels):
         p.a_data[c] = float(ad[c])
     # None = FR3D_SOLVER_AUTO: fp32 solver storage for one channel, fp64 for several
-    p.solver_fp64 = -1 if solver_fp64 is None else (int(solver_fp64) if solver_fp64 in (0, 1, 2, True, False) else 1)
+    p.solver_fp64 = -1 if solver_fp64 is None else (int(solver_fp64) if solver_fp64 in (0, 1, 2, 3, True, False) else 1)
     return p
 
 

@@ -209,8 +209,14 @@ def tensor_factors(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34):
     The reference's tensor is a sum of three outer products (core/optical_flow_3d.py:134-143), so
     the three leading eigenpairs reproduce it; psi_data's quadratic form d^T J d then becomes
     sum_k (a_k . d)^2, which is how the device evaluates it."""
-    Js = [np.asarray(j, dtype=np.float64) for j in (J11, J22, J33, J44, J12, J13, J23, J14, J24, J34)]
+    raw = [np.asarray(j) for j in (J11, J22, J33, J44, J12, J13, J23, J14, J24, J34)]
+    Js = [j.astype(np.float64, copy=False) for j in raw]
     shp = Js[0].shape
+    # relative size of the smallest eigenvalue a genuine rank-3 tensor may show: entries that are float32, or
+    # float64 holding float32-rounded values (get_motion_tensor_gc returns the engine's fp32 storage), carry
+    # ~6e-8 of rounding each, which lifts lambda_min to ~1e-7 of the trace; exact float64 tensors stay at ~1e-16
+    f32_grade = any(j.dtype != np.float64 or np.array_equal(j, j.astype(np.float32)) for j in raw)
+    rank_tol = 32 * float(np.finfo(np.float32).eps) if f32_grade else 1e-9
     M = np.empty(shp + (4, 4), np.float64)
     idx = {(0, 0): 0, (1, 1): 1, (2, 2): 2, (3, 3): 3, (0, 1): 4, (0, 2): 5, (1, 2): 6, (0, 3): 7, (1, 3): 8,
            (2, 3): 9}
@@ -221,9 +227,9 @@ def tensor_factors(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34):
     # the device solver keeps three factors: a tensor that is not (numerically) rank <= 3 -- e.g. one built by
     # another constancy assumption -- would silently be solved as a different system, so it is refused
     trace = np.maximum(lam.sum(axis=-1), 0.0)
-    if np.any(np.abs(lam[..., 0]) > 1e-9 * trace + 1e-300):
-        raise ValueError("level_solver: the motion tensor is not rank 3 (smallest eigenvalue exceeds 1e-9 of the trace); "
-                         "the device solver takes the gradient-constancy tensor of get_motion_tensor_gc")
+    if np.any(np.abs(lam[..., 0]) > rank_tol * trace + 1e-300):
+        raise ValueError(f"level_solver: the motion tensor is not rank 3 (smallest eigenvalue exceeds {rank_tol:.1e} of the "
+                         "trace); the device solver takes the gradient-constancy tensor of get_motion_tensor_gc")
     lam = np.clip(lam[..., 1:], 0.0, None)  # three leading eigenvalues
     V = V[..., :, 1:]
     A = np.sqrt(lam)[..., None, :] * V  # (..., 4, 3): column k = a_k

@@ -219,7 +219,8 @@ struct Engine {
     hipStream_t st = nullptr;
     std::map<std::string, DevBuf> bufs;
     std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
-    std::map<std::tuple<int, int, int, int, int>, SorSched> scheds;  // (Z,Y,X,iterations,lag) of a level
+    std::map<std::tuple<int, int, int, int, int>, SorSched> scheds;  // (Z,Y,X,iterations,lag) of a level (a_smooth != 1)
+    std::map<std::tuple<int, int, int, int, int, int, int>, SorChainSched> chain_scheds;  // (Z,Y,X,iterations,update_lag,rows,chain): a_smooth == 1
 
     // device tables of the compact skewed layout per level geometry (fr3d_internal.h: Skew::pb / cp)
     struct Compact {
@@ -250,12 +251,24 @@ struct Engine {
         return sk;
     }
 
-    const SorSched &sched(const Skew &sk, int iterations, int lag = 2)
+    const SorSched &sched(const Skew &sk, int iterations, int lag)
     {
+        FR3D_CHECK(lag == SM_LAG, "internal: per-iteration schedules serve the a_smooth != 1 kernels");
         auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, lag);
         auto it = scheds.find(key);
         if (it == scheds.end())  // the lag-4 (a_smooth != 1) kernels are written for 64 x 4 workgroups
-            it = scheds.emplace(key, build_sor_schedule(sk, iterations, lag == 2 ? sor_tile_rows(sk) : 4, lag)).first;
+            it = scheds.emplace(key, build_sor_schedule(sk, iterations, 4, lag)).first;
+        return it->second;
+    }
+    const SorChainSched &chain_sched(const Skew &sk, int iterations, int update_lag)
+    {
+        int by, nch;
+        sor_tile_shape(sk, by, nch);
+        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, update_lag, by, nch);
+        auto it = chain_scheds.find(key);
+        if (it == chain_scheds.end()) {
+            it = chain_scheds.emplace(key, build_sor_chain_schedule(sk, iterations, update_lag, by, nch)).first;
+        }
         return it->second;
     }
     // profiling
@@ -472,7 +485,9 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                                     int Z, int Y, int X, int C, const float *uvw_init, float *const *flow_out,
                                     int reserve_nb)
 {
-    const std::string sn = sizeof(S) == 8 ? "64" : "";  // separate workspaces per storage type
+    // separate workspaces per storage type
+    const std::string sn = std::is_same<S, pk42>::value ? "p42" : (sizeof(S) == 8 ? "64" : "");
+    using WT = typename StoWt<S>::type;
     FR3D_CHECK(p.a_smooth >= 0.0, "a_smooth must be >= 0");
     FR3D_CHECK(nb >= 1 && nb <= 64, "internal: bad batch size");
     const size_t nfull = (size_t)Z * Y * X;
@@ -493,27 +508,29 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         const Skew sk = e.compact_skew(lz, ly, lx);
         const size_t ns = (size_t)sk.total;
         const size_t nres = (size_t)std::max(nb, reserve_nb);  // slabs reserved (>= nb)
-        S *Mbuf = (S *)e.bufs["M_sk" + sn].ensure(ns * 9 * nres * sizeof(S));
-        S *Abuf = (S *)e.bufs["A_sk" + sn].ensure(ns * 12 * C * nres * sizeof(S));
-        S *wsk = (S *)e.bufs["w_sk" + sn].ensure(ns * C * sizeof(S));
-        S *Lbuf = (S *)e.bufs["L_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
-        S *dbuf = (S *)e.bufs["d_sk" + sn].ensure(ns * 3 * nres * sizeof(S));
+        // sizes and strides in storage elements (sto_elems: values for float / double, 4 dwords per 3 values for pk42)
+        const size_t e3 = (size_t)sto_elems<S>((long long)ns * 3), e9 = 3 * e3, e12 = 4 * e3;
+        S *Mbuf = (S *)e.bufs["M_sk" + sn].ensure(e9 * nres * sizeof(S));
+        S *Abuf = (S *)e.bufs["A_sk" + sn].ensure(e12 * C * nres * sizeof(S));
+        WT *wsk = (WT *)e.bufs["w_sk" + sn].ensure(ns * C * sizeof(WT));
+        S *Lbuf = (S *)e.bufs["L_sk" + sn].ensure(e3 * nres * sizeof(S));
+        S *dbuf = (S *)e.bufs["d_sk" + sn].ensure(e3 * nres * sizeof(S));
         SorArgsT<S> a;
         std::memset(&a, 0, sizeof(a));
         a.sk = sk;
         a.C = C;
         a.nvol = nb;
-        a.vsM = (long long)ns * 9;
-        a.vsA = (long long)ns * 12 * C;
-        a.vsL = (long long)ns * 3;
-        a.vsD = (long long)ns * 3;
+        a.vsM = (long long)e9;
+        a.vsA = (long long)e12 * C;
+        a.vsL = (long long)e3;
+        a.vsD = (long long)e3;
         // alpha schedule (:485-490) and alpha/h^2 (level_solver_3d.py:473-475)
         const double sc = (L.idx == min_level) ? 1.0 : std::pow(p.eta, -0.5 * (double)L.idx);
         a.ax = (sc * p.alpha[0]) / (hx * hx);
         a.ay = (sc * p.alpha[1]) / (hy * hy);
         a.az = (sc * p.alpha[2]) / (hz * hz);
         for (int c = 0; c < C; c++) {
-            a.A[c] = Abuf + (size_t)c * 12 * ns;
+            a.A[c] = Abuf + (size_t)c * e12;
             a.weight[c] = wsk + (size_t)c * ns;
             a.a_data[c] = p.a_data[c];
         }
@@ -522,8 +539,8 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         a.d = dbuf;
         {
             Span sp(e, FR3D_K_OTHER, 0, 0, 0);
-            for (int c = 0; c < C; c++) launch_skew_pack<float, S>(e.st, rp.wl[li] + (size_t)c * nl, 0, wsk + (size_t)c * ns, 1, sk);
-            if (fast) FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(S), e.st));
+            for (int c = 0; c < C; c++) launch_skew_pack<float, WT>(e.st, rp.wl[li] + (size_t)c * nl, 0, wsk + (size_t)c * ns, 1, sk);
+            if (fast) FR3D_HIP(hipMemsetAsync(dbuf, 0, e3 * nb * sizeof(S), e.st));
         }
 
         const std::string sfx = flip ? "_a" : "_b";
@@ -566,7 +583,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 for (int c = 0; c < C; c++) {
                     // only the square-root factors are needed: the solver rebuilds the tensor from
                     // them on psi-update iterations and keeps its own frozen 3x3 system in between
-                    S *Adst = Abuf + (size_t)b * a.vsA + (size_t)c * 12 * ns;
+                    S *Adst = Abuf + (size_t)b * a.vsA + (size_t)c * e12;
                     launch_motion_tensor_rec<S>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, hz, hy, hx, Adst, sk);
                 }
                 if (fast) launch_laplace_rec<S>(e.st, u[0], u[1], u[2], sk, a.ax, a.ay, a.az, Lbuf + (size_t)b * a.vsL);
@@ -576,11 +593,12 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         a.update_lag = p.update_lag;
         if (p.a_smooth == 1.0) {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
-            long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.sched(sk, p.iterations));
+            long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.chain_sched(sk, p.iterations, p.update_lag));
             // algorithmic traffic of the reference's update: 9C tensor entries + C (w psi) + 3 L + 3 d read, 3 d written,
-            // in the solver's storage type: 4 (10C + 9) B with fp32 storage, twice that with fp64 storage
-            sp.add((double)sizeof(S) * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
-        } else {
+            // in the solver's storage type: 4 (10C + 9) B with fp32 storage, twice that with fp64 storage, 4/3 of it
+            // with packed 42-bit storage
+            sp.add(sto_bytes_per_value<S>() * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
+        } else if constexpr (!std::is_same<S, pk42>::value) {
             // a_smooth != 1 (k_sor_smooth.hip): psi_smooth every iteration, triple-buffered increments; the volumes
             // of the batch share the launches; the result is copied into the batch slab the common tail reads
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
@@ -627,6 +645,8 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(S), e.st));
             }
             sp.add((double)sizeof(S) * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
+        } else {
+            throw Error("internal: packed solver storage serves the a_smooth == 1 sweep only");
         }
         // increments back to the natural layout, 5^3 median (:517-526), accumulate (:527-529)
         const bool med = std::min(lz, std::min(ly, lx)) > 5;
@@ -683,8 +703,11 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
 //  * several channels: fp64 storage, the reference iteration itself amplifies rounding there.
 static int solver_mode(const fr3d_params &p, int C, long long nvox)
 {
-    if (p.solver_fp64 >= 0) return p.solver_fp64;
-    return (C >= 2 || nvox > (1LL << 25)) ? 2 : 1;
+    int m = p.solver_fp64;
+    if (m < 0) m = C >= 2 ? 2 : (nvox > (1LL << 25) ? 3 : 1);
+    // packed 42-bit storage exists for the a_smooth == 1 sweep; the psi_smooth solver takes fp64 storage instead
+    if (m == 3 && p.a_smooth != 1.0) m = 2;
+    return m;
 }
 
 static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std::vector<Level> &lv, int min_level,
@@ -693,8 +716,10 @@ static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std:
 {
     fr3d_params p = p_in;
     p.solver_fp64 = solver_mode(p_in, C, (long long)Z * Y * X);
-    FR3D_CHECK(p.solver_fp64 >= 0 && p.solver_fp64 <= 2, "solver_fp64 must be FR3D_SOLVER_AUTO, 0, 1 or 2");
-    if (p.solver_fp64 == 2)
+    FR3D_CHECK(p.solver_fp64 >= 0 && p.solver_fp64 <= 3, "solver_fp64 must be FR3D_SOLVER_AUTO, 0, 1, 2 or 3");
+    if (p.solver_fp64 == 3)
+        get_displacement_core_t<pk42>(e, p, lv, min_level, rp, nb, moving, Z, Y, X, C, uvw_init, flow_out, reserve_nb);
+    else if (p.solver_fp64 == 2)
         get_displacement_core_t<double>(e, p, lv, min_level, rp, nb, moving, Z, Y, X, C, uvw_init, flow_out, reserve_nb);
     else
         get_displacement_core_t<float>(e, p, lv, min_level, rp, nb, moving, Z, Y, X, C, uvw_init, flow_out, reserve_nb);
@@ -705,7 +730,7 @@ static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std:
 // (29 skewed operand arrays per volume and channel set).
 static int g_batch_hint = 0;  // fr3d_set_batch()
 static bool g_fast_path = true;  // a_smooth == 1 of the call in progress (the psi_smooth path holds 13 more values per voxel)
-static bool g_fp64_storage = false;
+static double g_storage_bytes = 4.0;  // bytes per stored solver value of the call in progress
 
 // fr3d_set_batch(), else FR3D_BATCH, else 8
 static int batch_wanted()
@@ -728,7 +753,7 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
     }
     const double nfin = (double)F.z * F.y * F.x;
     // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
-    const double per_vol = (double)sk.total * (g_fp64_storage ? 8.0 : 4.0) * (12.0 * C + 9.0 + 6.0 + (g_fast_path ? 0.0 : 13.0)) + nfin * 4.0 * 9.0;
+    const double per_vol = (double)sk.total * g_storage_bytes * (12.0 * C + 9.0 + 6.0 + (g_fast_path ? 0.0 : 13.0)) + nfin * 4.0 * 9.0;
     // volume-independent scratch of the finest level: moving
     // level and its warp (2C), fp64 spline coefficients and the y-pass scratch (~4.2), increments and their median (6),
     // reference and weight pyramids (~4C)
@@ -869,7 +894,10 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     if (!rp_in) build_ref_pyramid(e, lv, ref_proc, weight, Z, Y, X, C, rp_own, "pb_");
     const RefPyramid &rp = rp_in ? *rp_in : rp_own;
     const size_t nv = (size_t)Z * Y * X;
-    g_fp64_storage = solver_mode(*p, C, (long long)Z * Y * X) == 2;
+    {
+        const int m = solver_mode(*p, C, (long long)Z * Y * X);
+        g_storage_bytes = m == 2 ? 8.0 : (m == 3 ? 16.0 / 3.0 : 4.0);
+    }
     g_fast_path = p->a_smooth == 1.0;
     const int B = T > 0 ? pick_batch(T, lv, C) : 1;
     // T volumes in ceil(T/B) lock-step batches of (nearly) equal size: 10 volumes at B = 4 run as
@@ -1153,6 +1181,8 @@ void fr3d_shutdown(void)
     g_eng.tables.clear();
     for (auto &kv : g_eng.scheds) free_sor_schedule(kv.second);
     g_eng.scheds.clear();
+    for (auto &kv : g_eng.chain_scheds) free_sor_chain_schedule(kv.second);
+    g_eng.chain_scheds.clear();
     for (auto &kv : g_eng.gkernels) (void)hipFree(kv.second.first);
     g_eng.gkernels.clear();
     for (auto &kv : g_eng.compacts) {
@@ -1594,7 +1624,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     a.update_lag = update_lag;
     if (fast) {
         launch_laplace_rec<float>(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lb);
-        launch_sor<float>(e.st, a, solver_fp64 != 0, e.sched(sk, iterations));
+        launch_sor<float>(e.st, a, solver_fp64 != 0, e.chain_sched(sk, iterations, update_lag));
     } else {
         float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);
         SmoothArgs<float> sa;
@@ -1664,6 +1694,22 @@ int fr3d_schedule(int Z, int Y, int X, double eta, int levels, int min_level, in
 }
 
 // ---- memory helpers -----------------------------------------------------------------------------
+
+long long fr3d_sor_schedule_check(int Z, int Y, int X, int iterations, int update_lag, int tile_rows, int chain,
+                                  long long *n_updates)
+{
+    try {
+        if (Z < 1 || Y < 1 || X < 1 || iterations < 0 || update_lag < 1 || tile_rows < 0 || chain < 0) {
+            g_err = "bad schedule arguments";
+            return -1;
+        }
+        if (tile_rows == 0 || chain == 0) sor_tile_shape(make_skew(Z, Y, X), tile_rows, chain);
+        return check_chain_schedule(Z, Y, X, iterations, update_lag, tile_rows, chain, n_updates);
+    } catch (const std::exception &ex) {
+        g_err = ex.what();
+        return -1;
+    }
+}
 
 void *fr3d_dev_malloc(size_t bytes)
 {

@@ -159,6 +159,19 @@ static inline long long make_compact_tables(int Z, int Y, int X, std::vector<lon
 // separate arrays, and a partly filled wave (rows of a hyperplane have every length from 1 to min(X,Y))
 // still moves long contiguous pieces: tools/microbench/row_layout.hip measures +18...+38 % useful bandwidth
 // for rows of 40...200 voxels against one array per operand.
+// packed 42-bit storage element (k_sor_core.h: Sto<pk42>): one dword; three values share four dwords
+struct pk42 {
+    uint32_t w;
+};
+// storage type of the per-voxel channel weights (resampled fp32 values: float is exact)
+template <typename S> struct StoWt { using type = S; };
+template <> struct StoWt<pk42> { using type = float; };
+// storage elements that hold `nvals` values (records of the sweep are multiples of 3 values)
+template <typename S> constexpr long long sto_elems(long long nvals) { return nvals; }
+template <> constexpr long long sto_elems<pk42>(long long nvals) { return nvals / 3 * 4; }
+template <typename S> constexpr double sto_bytes_per_value() { return (double)sizeof(S); }
+template <> constexpr double sto_bytes_per_value<pk42>() { return 16.0 / 3.0; }
+
 template <typename S>
 struct SorArgsT {
     // frozen per-voxel system of the current psi window, 9 per voxel: M11,M22,M33,M12,M13,M23,b_u,b_v,b_w
@@ -167,7 +180,7 @@ struct SorArgsT {
     // square-root factors of the motion tensor per channel, 12 per voxel, index 4*k + a (k = x,y,z equation;
     // a = u,v,w,t column): J = sum_k a_k a_k^T.  Read on psi-update iterations.
     const S *A[FR3D_MAX_CHANNELS];
-    const S *weight[FR3D_MAX_CHANNELS];  // one value per voxel (plain skewed arrays, shared by a batch)
+    const typename StoWt<S>::type *weight[FR3D_MAX_CHANNELS];  // one value per voxel (plain skewed arrays, shared by a batch)
     const S *L;  // alpha-weighted Laplacian of u,v,w (constant over the iterations), 3 per voxel
     S *d;        // du,dv,dw, 3 per voxel, updated in place
     Skew sk;
@@ -176,11 +189,12 @@ struct SorArgsT {
     int C;
     int iterations, update_lag;
     // batch of volumes solved in lock step by the same launches: pointers above are volume 0,
-    // volume v adds v*stride elements of S (weights are shared by all volumes of a batch)
+    // volume v adds v*stride storage elements (sto_elems; weights are shared by all volumes of a batch)
     int nvol;
     long long vsM, vsA, vsL, vsD;
-    // numerics experiments (FR3D_SOR_DBG, meaningful with S = double): round to fp32 when stored / read --
-    // 1 increments, 2 frozen system, 4 Laplacian terms, 8 factors (profiles/r02/numerics_512_rounding_groups.md)
+    // numerics experiments (builds with -DFR3D_EXPERIMENTS only; FR3D_SOR_DBG, meaningful with S = double): round
+    // to fp32 when stored / read -- 1 increments, 2 frozen system, 4 Laplacian terms, 8 factors
+    // (profiles/r02/numerics_512_rounding_groups.md)
     int dbg;
 };
 using SorArgs = SorArgsT<float>;
@@ -282,9 +296,9 @@ void launch_laplace_rec(hipStream_t st, const float *u, const float *v, const fl
 // bounding box (in tile units) of the valid part of hyperplane s = tau - 2t, so that only tiles that
 // can hold voxels are dispatched (an all-covering grid spends ~8 us per launch on empty workgroups).
 struct SorEntry {
-    int pre;               // tiles of this launch before this iteration
+    int pre;               // tiles of this launch before this group
     short kb0, njb;        // first k-tile, j-tiles per k-tile row (rows are left-aligned)
-    short pad0, pad1;
+    short toff, nit;       // first iteration of the group relative to the launch's t_lo; iterations in the group
 };
 #define SOR_LUT_SHIFT 6
 struct SorSched {
@@ -305,15 +319,37 @@ struct SorSched {
     int *bnd_meta = nullptr;                         // device, (first, count) per hyperplane
     int bnd_max = 0;                                 // largest bnd_count
 };
-// Tile = 64 lanes along j x `by` rows (2 by default; FR3D_SOR_BY overrides).
-int sor_tile_rows(const Skew &sk);
+// Schedule of the a_smooth == 1 sweep (k_sor.hip).  Every launch tau has two parts, each its own kernel:
+// part 0 = ordinary iterations, part 1 = psi-update iterations (t % update_lag == 0).  An entry of part 0 is a
+// CHAIN of up to `nch` consecutive ordinary iterations t0 .. t0+n-1: one workgroup (64 lanes x `by` rows x `nch`
+// chain positions) takes the tile (rows k.., lanes jj..) of iteration t0 on plane s0 = tau - 2 t0 and, at chain
+// position n, the rows k-n.. of iteration t0+n on plane s0 - 2n.  Plane s0-2n-1 is the "minus" neighbour plane of
+// position n and the "plus" neighbour plane of position n+1, the same rows and (to within one lane) the same
+// lanes of it: a chain of n iterations fetches n+1 neighbour planes instead of 2n, all of them written by the
+// PREVIOUS launch, so there is nothing to synchronise -- the sharing happens in the CU's L1 and the XCD's L2.
+struct SorChainSched {
+    struct Part {
+        std::vector<int> first, nent, ntiles, lut_first;  // per launch
+    };
+    std::vector<int> tau, t_lo;  // per launch
+    Part part[2];
+    SorEntry *entries = nullptr;  // device
+    int *lut = nullptr;           // device
+    int by = 2, nch = 1;
+};
+SorChainSched build_sor_chain_schedule(const Skew &sk, int iterations, int update_lag, int by, int nch);
+void free_sor_chain_schedule(SorChainSched &s);
+// host replay of the kernel's index arithmetic: 0 = every update issued exactly once in the right launch
+long long check_chain_schedule(int Z, int Y, int X, int iterations, int update_lag, int by, int nch, long long *n_updates);
+// workgroup shape of the sweep: rows per tile and chain positions
+void sor_tile_shape(const Skew &sk, int &by, int &nch);
 // iteration t works on hyperplane tau - lag*t in launch tau (lag 2: a_smooth == 1 kernel; lag 4 = SM_LAG:
 // the a_smooth != 1 kernels, whose P-stage and sweep share one schedule two launches apart)
 SorSched build_sor_schedule(const Skew &sk, int iterations, int by, int lag = 2);
 void free_sor_schedule(SorSched &s);
 // Runs all `iterations` pipelined hyperplane steps.  Returns the number of kernel launches.
 template <typename S>
-long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorSched &sched);
+long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorChainSched &sched);
 
 // K8 median (natural layout)
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);

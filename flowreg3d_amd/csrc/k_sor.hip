@@ -23,6 +23,8 @@
 // is evaluated inside the sweep on iterations with t % update_lag == 0 and stored as w*psi;
 // the u,v,w part of the stencil is iteration-invariant and precomputed once (k_laplace).
 #include <algorithm>
+#include <climits>
+#include <cstdio>
 #include <cstdlib>
 
 #include "fr3d_internal.h"
@@ -31,35 +33,39 @@
 namespace fr3d {
 
 #define SOR_BX 64
-#define SOR_BY_MAX 4  // rows of a tile = blockDim.y (1, 2 or 4; chosen per level, see sor_tile_rows)
+#define SOR_MAX_THREADS 1024  // 64 lanes x rows x chain positions of an ordinary-iteration workgroup
 
-template <typename R, typename S, int C>
-__global__ void __launch_bounds__(SOR_BX * SOR_BY_MAX)
-k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__restrict__ ent,
+template <typename R, typename S, int C, bool UPD>
+__global__ void __launch_bounds__(UPD ? 256 : SOR_MAX_THREADS)
+k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__restrict__ ent,
            const int *__restrict__ lut)
 {
     const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X;
-    // blockIdx.x enumerates the tiles of all in-flight iterations (schedule built on the host)
+    // blockIdx.x enumerates the tiles of all groups of this launch part (schedule built on the host)
     const int vol = blockIdx.y;
     const int b = blockIdx.x;
-    // find the iteration: the table gives the entry of the first tile of this tile group, a short
+    // find the group: the table gives the entry of the first tile of this tile group, a short
     // forward scan does the rest (a bisection costs ~7 dependent scalar loads before the first
     // vector load can be issued)
     int lo = lut[b >> SOR_LUT_SHIFT];
-    while (lo + 1 < nt && ent[lo + 1].pre <= b) lo++;
+    while (lo + 1 < nent && ent[lo + 1].pre <= b) lo++;
     const SorEntry en = ent[lo];
     const int local = b - en.pre;
-    const int t = t_lo + lo;
+    // a wave is one row of one chain position (blockDim.x == 64): row and iteration are wave-uniform, which
+    // keeps the row starts in SGPRs
+    const int n = __builtin_amdgcn_readfirstlane((int)threadIdx.z);
+    if (n >= en.nit) return;
+    const int t = t_lo + en.toff + n;
     const int s = tau - 2 * t;
-    // a wave is one row (blockDim.x == 64): its row number is wave-uniform, which keeps the row starts in SGPRs
-    const int k = (en.kb0 + local / en.njb) * (int)blockDim.y + __builtin_amdgcn_readfirstlane((int)threadIdx.y);
-    if (k >= Z) return;
+    const int k = (en.kb0 + local / en.njb) * (int)blockDim.y + __builtin_amdgcn_readfirstlane((int)threadIdx.y) - n;
+    if (k < 0 || k >= Z) return;
     const int r = s - k;                       // i + j of this row
+    if (r < 0 || r > X + Y - 2) return;
     const int jm0 = sk_jm(X, r);               // first valid j of the row (left-aligned storage)
     const int jj = (local % en.njb) * SOR_BX + threadIdx.x;
     const int j = jj + jm0;
     const int i = r - j;
-    if (r < 0 || j >= Y || i < 0) return;      // i < X holds by construction of jm0
+    if (j >= Y || i < 0) return;               // i < X holds by construction of jm0
 
     // voxel (record) indices of the voxel and of its six neighbours inside one volume's arrays: row start
     // (wave-uniform) + lane.  Compact layout: rows of the planes s-1, s, s+1 start at pb[.] - cp[.] (see Skew);
@@ -95,51 +101,238 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nt, const SorEntry *__res
     const R su_y = (R)qym.v[0] + (R)qyp.v[0], sv_y = (R)qym.v[1] + (R)qyp.v[1], sw_y = (R)qym.v[2] + (R)qyp.v[2];
     const R su_z = (R)qzm.v[0] + (R)qzp.v[0], sv_z = (R)qzm.v[1] + (R)qzp.v[1], sw_z = (R)qzm.v[2] + (R)qzp.v[2];
     R m[9];
-    const bool upd = (t % a.update_lag) == 0;
-    sor_system<R, S, C>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
+    sor_system<R, S, C, UPD>(a, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
     R du1, dv1, dw1;
     sor_relax<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,
                  dw1);
     Rec<S, 3> out;
-    out.v[0] = (S)du1;
-    out.v[1] = (S)dv1;
-    out.v[2] = (S)dw1;
-    if (a.dbg & 1) { out.v[0] = (S)(float)du1; out.v[1] = (S)(float)dv1; out.v[2] = (S)(float)dw1; }
+    out.v[0] = Sto<S>::quant(du1);
+    out.v[1] = Sto<S>::quant(dv1);
+    out.v[2] = Sto<S>::quant(dw1);
+#ifdef FR3D_EXPERIMENTS
+    if (a.dbg & 1) {
+        using V = typename Sto<S>::val;
+        out.v[0] = (V)(float)du1; out.v[1] = (V)(float)dv1; out.v[2] = (V)(float)dw1;
+    }
+#endif
     strec<S, 3>(D, c0, out);
 }
 
 template <typename R, typename S>
-static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo, int nt, int ntiles,
-                        const SorEntry *ent, const int *lut, int by)
+static void launch_part(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo, const SorChainSched &sc, size_t l, int part)
 {
-    dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, by);
-#define FR3D_SOR_CASE(CH)                                                                                  \
-    case CH: hipLaunchKernelGGL((k_sor_step<R, S, CH>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut); break;
-    switch (a.C) {
-        FR3D_SOR_CASE(1)
-        FR3D_SOR_CASE(2)
-        FR3D_SOR_CASE(3)
-        FR3D_SOR_CASE(4)
-        // 5..FR3D_MAX_CHANNELS channels: one instantiation with the channel loop bound read at run time
-        // (the loop already handles one channel at a time, k_sor_core.h; level_solver_3d.py:356-377 loops over any C)
-        default:
-            FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
-            hipLaunchKernelGGL((k_sor_step<R, S, 0>), grid, block, 0, st, a, tau, t_lo, nt, ent, lut);
-            break;
-    }
+    const SorChainSched::Part &P = sc.part[part];
+    const int ntiles = P.ntiles[l];
+    if (ntiles <= 0) return;
+    const SorEntry *ent = sc.entries + P.first[l];
+    const int *lut = sc.lut + P.lut_first[l];
+    const int nent = P.nent[l];
+    dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1);
+    if (part == 0) {
+        // ordinary iterations stream the frozen 3x3 system: one instantiation for every channel count
+        hipLaunchKernelGGL((k_sor_step<R, S, 1, false>), grid, dim3(SOR_BX, sc.by, sc.nch), 0, st, a, tau, t_lo, nent, ent, lut);
+    } else {
+        const dim3 block(SOR_BX, sc.by, 1);
+#define FR3D_SOR_CASE(CH)                                                                                     \
+    case CH: hipLaunchKernelGGL((k_sor_step<R, S, CH, true>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut); break;
+        switch (a.C) {
+            FR3D_SOR_CASE(1)
+            FR3D_SOR_CASE(2)
+            FR3D_SOR_CASE(3)
+            FR3D_SOR_CASE(4)
+            // 5..FR3D_MAX_CHANNELS channels: one instantiation with the channel loop bound read at run time
+            // (the loop already handles one channel at a time, k_sor_core.h; level_solver_3d.py:356-377 loops over any C)
+            default:
+                FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
+                hipLaunchKernelGGL((k_sor_step<R, S, 0, true>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut);
+                break;
+        }
 #undef FR3D_SOR_CASE
+    }
     FR3D_LAUNCH_CHECK();
 }
 
-int sor_tile_rows(const Skew &sk)
+void sor_tile_shape(const Skew &sk, int &by, int &nch)
 {
-    static const char *env = getenv("FR3D_SOR_BY");
-    if (env) {
-        const int v = atoi(env);
-        if (v == 1 || v == 2 || v == 4) return v;
-    }
     (void)sk;
-    return 2;  // 64 lanes x 2 rows: 1-2 % ahead of 4 rows at 256^3 and 512^3 with the record layout (1 row: -1 %)
+    by = 2;   // 64 lanes x 2 rows
+    nch = 4;  // x 4 chain positions (update_lag - 1 = 4 ordinary iterations between psi updates with the defaults)
+#ifdef FR3D_EXPERIMENTS
+    if (const char *env = getenv("FR3D_SOR_SHAPE")) {  // "<rows>x<chain>", e.g. 2x4
+        int b = 0, c = 0;
+        if (sscanf(env, "%dx%d", &b, &c) == 2 && (b == 1 || b == 2 || b == 4 || b == 8) && c >= 1 && c <= 8) {
+            by = b;
+            nch = c;
+        }
+    }
+#endif
+    while (SOR_BX * by * nch > SOR_MAX_THREADS) nch--;
+}
+
+// rows [klo, khi] of hyperplane s that hold voxels, and the longest of them
+static inline bool plane_rows(const Skew &sk, int s, int &klo, int &khi)
+{
+    klo = std::max(0, s - (sk.X - 1) - (sk.Y - 1));
+    khi = std::min(sk.Z - 1, s);
+    return s >= 0 && s < sk.S && klo <= khi;
+}
+static inline int plane_maxlen(const Skew &sk, int s, int klo, int khi)
+{
+    // len(r) = min(Y-1, r) - jm(r) + 1 rises to min(X,Y) and falls again: evaluate the ends and the plateau
+    int maxlen = 0;
+    for (int k = klo; k <= khi; k++) {
+        const int r = s - k;
+        const int len = std::min(sk.Y - 1, r) - sk_jm(sk.X, r) + 1;
+        if (len > maxlen) maxlen = len;
+    }
+    return maxlen;
+}
+
+// host side of the schedule: entries and group tables of every launch part (no device calls)
+void make_chain_entries(const Skew &sk, int T, int lagU, int by, int nch, SorChainSched &sc, std::vector<SorEntry> &ent,
+                        std::vector<int> &lut)
+{
+    sc.by = by;
+    sc.nch = nch;
+    if (T <= 0) return;
+    FR3D_CHECK(T <= 32767, "SOR schedule: more than 32767 iterations");
+    FR3D_CHECK(lagU >= 1 && by >= 1 && nch >= 1 && SOR_BX * by * nch <= SOR_MAX_THREADS, "SOR schedule: bad tile shape");
+    const int S = sk.S;
+    const int last = (S - 1) + 2 * (T - 1);
+    for (int tau = 0; tau <= last; tau++) {
+        int t_lo = tau - (S - 1);
+        t_lo = t_lo <= 0 ? 0 : (t_lo + 1) / 2;
+        int t_hi = tau / 2;
+        if (t_hi > T - 1) t_hi = T - 1;
+        if (t_lo > t_hi) continue;
+        sc.tau.push_back(tau);
+        sc.t_lo.push_back(t_lo);
+        for (int part = 0; part < 2; part++) {
+            SorChainSched::Part &P = sc.part[part];
+            P.first.push_back((int)ent.size());
+            int pre = 0, nent = 0;
+            int t = t_lo;
+            while (t <= t_hi) {
+                const bool psi = (t % lagU) == 0;
+                if (psi != (part == 1)) { t++; continue; }
+                // the group: one psi iteration, or a run of up to nch consecutive ordinary iterations
+                int n = 1;
+                if (part == 0)
+                    while (n < nch && t + n <= t_hi && ((t + n) % lagU) != 0) n++;
+                // tile rows in the coordinates of chain position 0: position q handles row k - q of plane s0 - 2q
+                int kmin = INT_MAX, kmax = INT_MIN, maxlen = 0;
+                for (int q = 0; q < n; q++) {
+                    int klo, khi;
+                    const int s = tau - 2 * (t + q);
+                    if (!plane_rows(sk, s, klo, khi)) continue;
+                    kmin = std::min(kmin, klo + q);
+                    kmax = std::max(kmax, khi + q);
+                    maxlen = std::max(maxlen, plane_maxlen(sk, s, klo, khi));
+                }
+                if (maxlen > 0) {
+                    SorEntry e;
+                    e.pre = pre;
+                    e.kb0 = (short)(kmin / by);
+                    e.njb = (short)cdiv(maxlen, SOR_BX);
+                    e.toff = (short)(t - t_lo);
+                    e.nit = (short)n;
+                    pre += (kmax / by - kmin / by + 1) * e.njb;
+                    ent.push_back(e);
+                    nent++;
+                }
+                t += n;
+            }
+            P.nent.push_back(nent);
+            P.ntiles.push_back(pre);
+            // group table of this launch part
+            P.lut_first.push_back((int)lut.size());
+            const size_t e0 = (size_t)P.first.back();
+            int cur = 0;
+            for (int g = 0; (g << SOR_LUT_SHIFT) < pre; g++) {
+                const int b0 = g << SOR_LUT_SHIFT;
+                while (cur + 1 < nent && ent[e0 + cur + 1].pre <= b0) cur++;
+                lut.push_back(cur);
+            }
+        }
+    }
+}
+
+SorChainSched build_sor_chain_schedule(const Skew &sk, int T, int lagU, int by, int nch)
+{
+    SorChainSched sc;
+    std::vector<SorEntry> ent;
+    std::vector<int> lut;
+    make_chain_entries(sk, T, lagU, by, nch, sc, ent, lut);
+    if (T <= 0) return sc;
+    FR3D_HIP(hipMalloc((void **)&sc.entries, std::max<size_t>(ent.size(), 1) * sizeof(SorEntry)));
+    FR3D_HIP(hipMemcpy(sc.entries, ent.data(), ent.size() * sizeof(SorEntry), hipMemcpyHostToDevice));
+    FR3D_HIP(hipMalloc((void **)&sc.lut, std::max<size_t>(lut.size(), 1) * sizeof(int)));
+    FR3D_HIP(hipMemcpy(sc.lut, lut.data(), lut.size() * sizeof(int), hipMemcpyHostToDevice));
+    return sc;
+}
+
+// Host replay of the kernel's index arithmetic over a whole schedule (no device involved): every voxel update
+// (t, k, j, i) must be issued exactly once, by the launch tau = i + j + k + 2t, in the part that matches the kind
+// of iteration t.  Returns 0 and the number of updates, or the number of violations.
+long long check_chain_schedule(int Z, int Y, int X, int T, int lagU, int by, int nch, long long *n_updates)
+{
+    const Skew sk = make_skew(Z, Y, X);
+    SorChainSched sc;
+    std::vector<SorEntry> ent;
+    std::vector<int> lut;
+    make_chain_entries(sk, T, lagU, by, nch, sc, ent, lut);
+    const size_t nv = (size_t)Z * Y * X;
+    std::vector<unsigned char> seen((size_t)std::max(T, 0) * nv, 0);
+    long long bad = 0, total = 0;
+    for (size_t l = 0; l < sc.tau.size(); l++) {
+        for (int part = 0; part < 2; part++) {
+            const SorChainSched::Part &P = sc.part[part];
+            const SorEntry *en_ = ent.data() + P.first[l];
+            const int *lu = lut.data() + P.lut_first[l];
+            const int nent = P.nent[l], tau = sc.tau[l], t_lo = sc.t_lo[l];
+            const int nz = part == 0 ? nch : 1;
+            for (int b = 0; b < P.ntiles[l]; b++) {
+                int lo = lu[b >> SOR_LUT_SHIFT];
+                while (lo + 1 < nent && en_[lo + 1].pre <= b) lo++;
+                const SorEntry en = en_[lo];
+                const int local = b - en.pre;
+                if (local < 0) { bad++; continue; }
+                for (int n = 0; n < nz; n++)
+                    for (int ty = 0; ty < by; ty++) {
+                        if (n >= en.nit) continue;
+                        const int t = t_lo + en.toff + n;
+                        if (t < 0 || t >= T || ((t % lagU) == 0) != (part == 1)) { bad++; continue; }
+                        const int s = tau - 2 * t;
+                        const int k = (en.kb0 + local / en.njb) * by + ty - n;
+                        if (k < 0 || k >= Z) continue;
+                        const int r = s - k;
+                        if (r < 0 || r > X + Y - 2) continue;
+                        const int jm0 = sk_jm(X, r);
+                        for (int lane = 0; lane < SOR_BX; lane++) {
+                            const int jj = (local % en.njb) * SOR_BX + lane;
+                            const int j = jj + jm0, i = r - j;
+                            if (j >= Y || i < 0) continue;
+                            if (i >= X) { bad++; continue; }
+                            unsigned char &c = seen[(size_t)t * nv + ((size_t)k * Y + j) * X + i];
+                            if (c) bad++;
+                            c = 1;
+                            total++;
+                        }
+                    }
+            }
+        }
+    }
+    for (unsigned char c : seen) bad += c ? 0 : 1;
+    if (n_updates) *n_updates = total;
+    return bad;
+}
+
+void free_sor_chain_schedule(SorChainSched &s)
+{
+    if (s.entries) (void)hipFree(s.entries);
+    if (s.lut) (void)hipFree(s.lut);
+    s.entries = nullptr;
+    s.lut = nullptr;
 }
 
 SorSched build_sor_schedule(const Skew &sk, int T, int by, int lag)
@@ -173,7 +366,8 @@ SorSched build_sor_schedule(const Skew &sk, int T, int by, int lag)
             const int klo = std::max(0, s - (X - 1) - (Y - 1)), khi = std::min(Z - 1, s);
             SorEntry e;
             e.pre = pre;
-            e.pad0 = e.pad1 = 0;
+            e.toff = (short)(t - t_lo);
+            e.nit = 1;
             e.kb0 = 0;
             e.njb = 1;
             if (klo <= khi) {
@@ -254,24 +448,31 @@ void free_sor_schedule(SorSched &s)
 }
 
 template <typename S>
-long long launch_sor(hipStream_t st, const SorArgsT<S> &a_in, bool fp64, const SorSched &sc)
+long long launch_sor(hipStream_t st, const SorArgsT<S> &a_in, bool fp64, const SorChainSched &sc)
 {
     SorArgsT<S> a = a_in;
-    const char *dbg_env = getenv("FR3D_SOR_DBG");  // numerics experiments, see SorArgsT::dbg
-    a.dbg = dbg_env ? atoi(dbg_env) : 0;
+    a.dbg = 0;
+#ifdef FR3D_EXPERIMENTS
+    if (const char *dbg_env = getenv("FR3D_SOR_DBG")) a.dbg = atoi(dbg_env);  // numerics experiments, see SorArgsT::dbg
+#endif
     long long launches = 0;
     for (size_t l = 0; l < sc.tau.size(); l++) {
-        if (sc.ntiles[l] <= 0) continue;
-        const SorEntry *ent = sc.entries + sc.first[l];
-        const int *lut = sc.lut + sc.lut_first[l];
-        if (fp64 || sizeof(S) == 8) launch_step<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent, lut, sc.by);
-        else launch_step<float, S>(st, a, sc.tau[l], sc.t_lo[l], sc.nt[l], sc.ntiles[l], ent, lut, sc.by);
-        launches++;
+        for (int part = 0; part < 2; part++) {
+            if (sc.part[part].ntiles[l] <= 0) continue;
+            if constexpr (Sto<S>::wide) {
+                launch_part<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc, l, part);
+            } else {
+                if (fp64) launch_part<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc, l, part);
+                else launch_part<float, S>(st, a, sc.tau[l], sc.t_lo[l], sc, l, part);
+            }
+            launches++;
+        }
     }
     return launches;
 }
-template long long launch_sor<float>(hipStream_t, const SorArgsT<float> &, bool, const SorSched &);
-template long long launch_sor<double>(hipStream_t, const SorArgsT<double> &, bool, const SorSched &);
+template long long launch_sor<float>(hipStream_t, const SorArgsT<float> &, bool, const SorChainSched &);
+template long long launch_sor<double>(hipStream_t, const SorArgsT<double> &, bool, const SorChainSched &);
+template long long launch_sor<pk42>(hipStream_t, const SorArgsT<pk42> &, bool, const SorChainSched &);
 
 // ---- layout conversion and the iteration-invariant stencil part -------------------------------
 
@@ -280,9 +481,9 @@ template long long launch_sor<double>(hipStream_t, const SorArgsT<double> &, boo
 // along the tile's anti-diagonals (x+y constant => same hyperplane and row, consecutive j => consecutive
 // records), so both sides are coalesced.
 #define PKX 32
-template <typename TS, typename TD, int NREC, int TY>
+template <typename TS, typename TD, int NREC, int TY, bool TO_SKEW>
 __global__ void __launch_bounds__(256)
-k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ dst, const Skew sk, int to_skew)
+k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ dst, const Skew sk)
 {
     const int Y = sk.Y, X = sk.X;
     // pitch 34: element (ly, d - ly) of a diagonal sits at 33*ly + d -> consecutive banks for consecutive ly
@@ -292,7 +493,7 @@ k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ d
     const int x0 = (blockIdx.x % txn) * PKX, y0 = (blockIdx.x / txn) * TY;
     const int z = blockIdx.y;
     const int lane = threadIdx.x % PKX, grp = threadIdx.x / PKX;  // 8 groups of 32
-    if (to_skew) {
+    if constexpr (TO_SKEW) {
 #pragma unroll
         for (int a = 0; a < NREC; a++) {
             TS v[(TY + 7) / 8];
@@ -322,9 +523,9 @@ k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ d
             tile_diag<TY>(lane, m, ly, lx);
             const int y = y0 + ly, x = x0 + lx;
             if (y < Y && x < X) {
-                const TS *o = src + (size_t)sk_index(sk, z, y, x) * NREC;
+                const Rec<TS, NREC> o = ldrec<TS, NREC>(src, sk_index(sk, z, y, x));
 #pragma unroll
-                for (int a = 0; a < NREC; a++) tile[a][ly][lx] = (TD)o[a];
+                for (int a = 0; a < NREC; a++) tile[a][ly][lx] = (TD)o.v[a];
             }
         }
         __syncthreads();
@@ -338,29 +539,29 @@ k_skew_pack(const TS *__restrict__ src, long long src_stride, TD *__restrict__ d
     }
 }
 
-template <typename TS, typename TD, int NREC>
-static void launch_pack_t(hipStream_t st, const TS *src, long long stride, TD *dst, const Skew &sk, int to_skew)
+template <typename TS, typename TD, int NREC, bool TO_SKEW>
+static void launch_pack_t(hipStream_t st, const TS *src, long long stride, TD *dst, const Skew &sk)
 {
     // LDS per workgroup: NREC * TY * 34 values; 12 fp64 values per voxel need the 16-row tile
     constexpr int TY = (sizeof(TD) * NREC > 48) ? 16 : 32;
     FR3D_CHECK(sk.Z <= 65535, "skew transposes: z axis longer than 65535");
     dim3 grid(cdiv(sk.X, PKX) * cdiv(sk.Y, TY), sk.Z);
-    hipLaunchKernelGGL((k_skew_pack<TS, TD, NREC, TY>), grid, dim3(256), 0, st, src, stride, dst, sk, to_skew);
+    hipLaunchKernelGGL((k_skew_pack<TS, TD, NREC, TY, TO_SKEW>), grid, dim3(256), 0, st, src, stride, dst, sk);
     FR3D_LAUNCH_CHECK();
 }
 
 template <typename TS, typename TD>
 void launch_skew_pack(hipStream_t st, const TS *src, long long src_stride, TD *dst, int nrec, const Skew &sk)
 {
-    if (nrec == 1) launch_pack_t<TS, TD, 1>(st, src, src_stride, dst, sk, 1);
-    else if (nrec == 3) launch_pack_t<TS, TD, 3>(st, src, src_stride, dst, sk, 1);
-    else if (nrec == 12) launch_pack_t<TS, TD, 12>(st, src, src_stride, dst, sk, 1);
+    if (nrec == 1) launch_pack_t<TS, TD, 1, true>(st, src, src_stride, dst, sk);
+    else if (nrec == 3) launch_pack_t<TS, TD, 3, true>(st, src, src_stride, dst, sk);
+    else if (nrec == 12) launch_pack_t<TS, TD, 12, true>(st, src, src_stride, dst, sk);
     else throw Error("internal: records of 1, 3 or 12 values");
 }
 template <typename TS, typename TD>
 void launch_unskew_unpack(hipStream_t st, const TS *src, TD *dst, long long dst_stride, int nrec, const Skew &sk)
 {
-    if (nrec == 3) launch_pack_t<TS, TD, 3>(st, src, dst_stride, dst, sk, 0);
+    if (nrec == 3) launch_pack_t<TS, TD, 3, false>(st, src, dst_stride, dst, sk);
     else throw Error("internal: records of 3 values");
 }
 template void launch_skew_pack<float, float>(hipStream_t, const float *, long long, float *, int, const Skew &);
@@ -368,6 +569,7 @@ template void launch_skew_pack<double, double>(hipStream_t, const double *, long
 template void launch_skew_pack<float, double>(hipStream_t, const float *, long long, double *, int, const Skew &);
 template void launch_unskew_unpack<float, float>(hipStream_t, const float *, float *, long long, int, const Skew &);
 template void launch_unskew_unpack<double, float>(hipStream_t, const double *, float *, long long, int, const Skew &);
+template void launch_unskew_unpack<pk42, float>(hipStream_t, const pk42 *, float *, long long, int, const Skew &);
 
 // L = ax*(u_ip + u_im - 2u) + ay*(...) + az*(...) with edge-padded u (add_boundary,
 // core/optical_flow_3d.py:88), evaluated in fp64 from the fp32-exact level flow.
@@ -378,7 +580,7 @@ __global__ void __launch_bounds__(256)
 k_laplace_rec(const float *__restrict__ u, const float *__restrict__ v, const float *__restrict__ w, const Skew sk,
               double ax, double ay, double az, TL *__restrict__ dst)
 {
-    __shared__ TL tile[3][32][PKX + 2];
+    __shared__ typename Sto<TL>::val tile[3][32][PKX + 2];
     const int Z = sk.Z, Y = sk.Y, X = sk.X;
     const int txn = (X + PKX - 1) / PKX;
     const int x0 = (blockIdx.x % txn) * PKX, y0 = (blockIdx.x / txn) * 32;
@@ -400,7 +602,7 @@ k_laplace_rec(const float *__restrict__ u, const float *__restrict__ v, const fl
                 double acc = ax * ((double)q[xp] + (double)q[xm] - 2.0 * c);
                 acc += ay * ((double)q[yp] + (double)q[ym] - 2.0 * c);
                 acc += az * ((double)q[zp] + (double)q[zm] - 2.0 * c);
-                tile[d][ly][lane] = (TL)acc;
+                tile[d][ly][lane] = Sto<TL>::quant(acc);
             }
         }
     }
@@ -410,10 +612,11 @@ k_laplace_rec(const float *__restrict__ u, const float *__restrict__ v, const fl
         tile_diag<32>(lane, m, ly, lx);
         const int y = y0 + ly, x = x0 + lx;
         if (y < Y && x < X) {
-            TL *o = dst + (size_t)sk_index(sk, z, y, x) * 3;
-            o[0] = tile[0][ly][lx];
-            o[1] = tile[1][ly][lx];
-            o[2] = tile[2][ly][lx];
+            Rec<TL, 3> o;
+            o.v[0] = tile[0][ly][lx];
+            o.v[1] = tile[1][ly][lx];
+            o.v[2] = tile[2][ly][lx];
+            strec<TL, 3>(dst, sk_index(sk, z, y, x), o);
         }
     }
 }
@@ -431,5 +634,7 @@ template void launch_laplace_rec<float>(hipStream_t, const float *, const float 
                                         double, double, float *);
 template void launch_laplace_rec<double>(hipStream_t, const float *, const float *, const float *, const Skew &, double,
                                          double, double, double *);
+template void launch_laplace_rec<pk42>(hipStream_t, const float *, const float *, const float *, const Skew &, double,
+                                       double, double, pk42 *);
 
 }  // namespace fr3d

@@ -3,6 +3,8 @@
 // :472-493 (stencil), :503-540 (du -> dv -> dw relaxation with omega = 1.95).
 #pragma once
 
+#include <type_traits>
+
 #include "fr3d_internal.h"
 
 namespace fr3d {
@@ -13,37 +15,112 @@ template <typename R> __device__ __forceinline__ R fma_(R a, R b, R c);
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
 
+// ---- storage formats of the solver operands -------------------------------------------------------------
+// float / double: plain arrays.  pk42 (fr3d_params.solver_fp64 == 3): three values share 16 bytes -- the upper 42
+// bits of each value's fp64 pattern (sign, 11 exponent bits, 30 mantissa bits: 31 significant bits, 128x finer than
+// fp32) -- dwords 0..2 hold the high words, dword 3 the three 10-bit continuations.  Decoding is two integer
+// operations per value and no conversion (the register pair IS the double); a record of N values (N a multiple
+// of 3: every record of the sweep is) takes 4N/3 dwords and is fetched as N/3 dwordx4 loads, 16-B aligned.
+// Why: at 512^3 every operand group held in fp32 costs ~1e-4 of flow error (profiles/r02/numerics_512_*), fp64
+// storage doubles the sweep's bytes; 42 bits keep the error at the fp64 level for 2/3 of its bytes.
+template <typename S> struct Sto;
+template <> struct Sto<float> {
+    using val = float;   // type of a decoded value
+    using wt = float;    // storage type of the per-voxel channel weights
+    static constexpr bool wide = false;  // fp64-grade storage: fp64 pow and fp64 update arithmetic
+    __host__ __device__ static constexpr long long elems(long long nvals) { return nvals; }
+    static constexpr double bytes_per_value = 4.0;
+    __device__ __forceinline__ static float quant(float x) { return x; }
+    __device__ __forceinline__ static float quant(double x) { return (float)x; }
+};
+template <> struct Sto<double> {
+    using val = double;
+    using wt = double;
+    static constexpr bool wide = true;
+    __host__ __device__ static constexpr long long elems(long long nvals) { return nvals; }
+    static constexpr double bytes_per_value = 8.0;
+    __device__ __forceinline__ static double quant(double x) { return x; }
+};
+#define PK42_ROUND (1ull << 21)
+#define PK42_MASK (~((1ull << 22) - 1ull))
+template <> struct Sto<pk42> {
+    using val = double;
+    using wt = float;  // weights are resampled fp32 values: exact in float
+    static constexpr bool wide = true;
+    __host__ __device__ static constexpr long long elems(long long nvals) { return nvals / 3 * 4; }
+    static constexpr double bytes_per_value = 16.0 / 3.0;
+    // round to nearest (ties away from zero) at bit 22 of the fp64 pattern; inf stays inf
+    __device__ __forceinline__ static double quant(double x)
+    {
+        return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(x) + PK42_ROUND) & PK42_MASK));
+    }
+};
+
 // A record of N consecutive values of one voxel; loading it as one object lets the compiler emit wide
-// global loads (dwordx3 / dwordx4) instead of N dword loads.
+// global loads (dwordx3 / dwordx4) instead of N dword loads.  `v` holds DECODED values.
 template <typename S, int N>
 struct Rec {
-    S v[N];
+    typename Sto<S>::val v[N];
 };
 template <typename S, int N>
 __device__ __forceinline__ Rec<S, N> ldrec(const S *base, long long voxel)
 {
-    return *reinterpret_cast<const Rec<S, N> *>(base + voxel * N);
+    if constexpr (std::is_same<S, pk42>::value) {
+        static_assert(N % 3 == 0, "pk42 records hold triples");
+        const uint4 *p = reinterpret_cast<const uint4 *>(base) + voxel * (N / 3);
+        Rec<S, N> r;
+#pragma unroll
+        for (int g = 0; g < N / 3; g++) {
+            const uint4 q = p[g];
+            r.v[3 * g + 0] = __hiloint2double((int)q.x, (int)((q.w & 0x3FFu) << 22));
+            r.v[3 * g + 1] = __hiloint2double((int)q.y, (int)(((q.w >> 10) & 0x3FFu) << 22));
+            r.v[3 * g + 2] = __hiloint2double((int)q.z, (int)((q.w >> 20) << 22));
+        }
+        return r;
+    } else {
+        return *reinterpret_cast<const Rec<S, N> *>(base + voxel * N);
+    }
 }
+// values must already be representable (Sto<S>::quant) -- the bits below the format are dropped
 template <typename S, int N>
 __device__ __forceinline__ void strec(S *base, long long voxel, const Rec<S, N> &r)
 {
-    *reinterpret_cast<Rec<S, N> *>(base + voxel * N) = r;
+    if constexpr (std::is_same<S, pk42>::value) {
+        uint4 *p = reinterpret_cast<uint4 *>(base) + voxel * (N / 3);
+#pragma unroll
+        for (int g = 0; g < N / 3; g++) {
+            const unsigned long long b0 = (unsigned long long)__double_as_longlong(r.v[3 * g + 0]);
+            const unsigned long long b1 = (unsigned long long)__double_as_longlong(r.v[3 * g + 1]);
+            const unsigned long long b2 = (unsigned long long)__double_as_longlong(r.v[3 * g + 2]);
+            uint4 q;
+            q.x = (unsigned)(b0 >> 32);
+            q.y = (unsigned)(b1 >> 32);
+            q.z = (unsigned)(b2 >> 32);
+            q.w = ((unsigned)b0 >> 22) | (((unsigned)b1 >> 22) << 10) | (((unsigned)b2 >> 22) << 20);
+            p[g] = q;
+        }
+    } else {
+        *reinterpret_cast<Rec<S, N> *>(base + voxel * N) = r;
+    }
 }
 
 // The 3x3 system of one voxel for the current psi window: m[0..5] = M11,M22,M33,M12,M13,M23 with
 // M = sum_c w_c psi_c J_c, m[6..8] = b = L - sum_c w_c psi_c (J14,J24,J34)_c.  psi is frozen between
-// psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration (`upd`)
+// psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration (UPD)
 // builds them from the square-root factors and, when `store`, writes them; the other iterations
 // stream the 9 stored values -- independent of the channel count.  `e` is the voxel's index inside one
 // volume's arrays, vM/vA/vL the (wave-uniform) element offsets of the volume's slab.
-template <typename R, typename S, int C>
-__device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool store, long long vM, long long vA,
+// UPD is a template argument: the two kinds of iteration are separate kernels, because the psi branch keeps up
+// to 158 VGPRs live (fp64 storage, several channels) where an ordinary iteration needs 55-80 -- in one kernel the
+// ordinary iterations (4 of 5) would run at the psi branch's occupancy.
+template <typename R, typename S, int C, bool UPD>
+__device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool store, long long vM, long long vA,
                                            long long vL, long long e, R du0, R dv0, R dw0, R (&m)[9])
 {
-    if (upd) {
+    using V = typename Sto<S>::val;
+    if constexpr (UPD) {
         R M11 = 0, M22 = 0, M33 = 0, M12 = 0, M13 = 0, M23 = 0, bu = 0, bv = 0, bw = 0;
-        // one channel at a time: unrolling over channels keeps 12C factors live and costs the ordinary
-        // iterations (4 of 5) their occupancy
+        // one channel at a time: unrolling over channels keeps 12C factors live
         const int nch = C > 0 ? C : a.C;  // C == 0: channel count at run time (5..FR3D_MAX_CHANNELS channels)
 #pragma unroll 1
         for (int c = 0; c < nch; c++) {
@@ -52,11 +129,13 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
             // square-root factors (see k_tensor.hip) -- algebraically the reference's expression,
             // but stable with fp32 storage.
             Rec<S, 12> fr = ldrec<S, 12>(a.A[c] + vA, e);
+#ifdef FR3D_EXPERIMENTS
             if (a.dbg & 8) {
 #pragma unroll
-                for (int q = 0; q < 12; q++) fr.v[q] = (S)(float)fr.v[q];
+                for (int q = 0; q < 12; q++) fr.v[q] = (V)(float)fr.v[q];
             }
-            const S *f = fr.v;
+#endif
+            const V *f = fr.v;
             double wt = (double)a.weight[c][e];
             const double adc = a.a_data[c];
             if (adc != 1.0) {
@@ -68,12 +147,12 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
                                    fma((double)f[4 * k + 2], w_, (double)f[4 * k + 3])));
                     val = fma(r, r, val);
                 }
-                // fp32 powf (~1 ulp): the products below are stored in fp32 anyway, and the fp64
+                // fp32 powf (~1 ulp) with fp32 storage: the products below are stored in fp32 anyway, and the fp64
                 // pow's ~600-instruction dependent chain set a ~6 us latency floor on every launch
-                if (sizeof(S) == 8) wt *= adc * pow(val + 1e-6, adc - 1.0);  // reference-grade mode
+                if (Sto<S>::wide) wt *= adc * pow(val + 1e-6, adc - 1.0);  // reference-grade modes
                 else wt *= adc * (double)powf((float)(val + 1e-6), (float)(adc - 1.0));
             }
-            const R w = (R)(S)wt;
+            const R w = (R)Sto<S>::quant(wt);
             const R x0 = (R)f[0], x1 = (R)f[1], x2 = (R)f[2], x3 = (R)f[3];
             const R y0 = (R)f[4], y1 = (R)f[5], y2 = (R)f[6], y3 = (R)f[7];
             const R z0 = (R)f[8], z1 = (R)f[9], z2 = (R)f[10], z3 = (R)f[11];
@@ -88,18 +167,22 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
             bw = fma_<R>(w, fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3)), bw);
         }
         Rec<S, 3> lr = ldrec<S, 3>(a.L + vL, e);
-        if (a.dbg & 4) { lr.v[0] = (S)(float)lr.v[0]; lr.v[1] = (S)(float)lr.v[1]; lr.v[2] = (S)(float)lr.v[2]; }
+#ifdef FR3D_EXPERIMENTS
+        if (a.dbg & 4) { lr.v[0] = (V)(float)lr.v[0]; lr.v[1] = (V)(float)lr.v[1]; lr.v[2] = (V)(float)lr.v[2]; }
+#endif
         const R b_u = (R)lr.v[0] - bu;
         const R b_v = (R)lr.v[1] - bv;
         const R b_w = (R)lr.v[2] - bw;
         Rec<S, 9> mr;
-        mr.v[0] = (S)M11; mr.v[1] = (S)M22; mr.v[2] = (S)M33;
-        mr.v[3] = (S)M12; mr.v[4] = (S)M13; mr.v[5] = (S)M23;
-        mr.v[6] = (S)b_u; mr.v[7] = (S)b_v; mr.v[8] = (S)b_w;
+        mr.v[0] = Sto<S>::quant(M11); mr.v[1] = Sto<S>::quant(M22); mr.v[2] = Sto<S>::quant(M33);
+        mr.v[3] = Sto<S>::quant(M12); mr.v[4] = Sto<S>::quant(M13); mr.v[5] = Sto<S>::quant(M23);
+        mr.v[6] = Sto<S>::quant(b_u); mr.v[7] = Sto<S>::quant(b_v); mr.v[8] = Sto<S>::quant(b_w);
+#ifdef FR3D_EXPERIMENTS
         if (a.dbg & 2) {
 #pragma unroll
-            for (int q = 0; q < 9; q++) mr.v[q] = (S)(float)mr.v[q];
+            for (int q = 0; q < 9; q++) mr.v[q] = (V)(float)mr.v[q];
         }
+#endif
         if (store) strec<S, 9>(a.M + vM, e, mr);
         // use the stored (rounded) values so update and non-update iterations see one system
 #pragma unroll

@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "fr3d_internal.h"
+#include "k_sor_core.h"
 
 namespace fr3d {
 
@@ -193,7 +194,7 @@ template <typename TA, int TY>
 __global__ void __launch_bounds__(256)
 k_motion_tensor_rec(Img f1, Img f2, TensorScale hs, TA *__restrict__ dst, const Skew sk, int dbg)
 {
-    __shared__ TA tile[12][TY][TPX + 2];  // pitch 34: a diagonal's elements fall into consecutive banks
+    __shared__ typename Sto<TA>::val tile[12][TY][TPX + 2];  // pitch 34: a diagonal's elements fall into consecutive banks
     const int Y = f1.Y, X = f1.X;
     const int txn = (X + TPX - 1) / TPX;
     const int x0 = (blockIdx.x % txn) * TPX, y0 = (blockIdx.x / txn) * TY;
@@ -206,7 +207,7 @@ k_motion_tensor_rec(Img f1, Img f2, TensorScale hs, TA *__restrict__ dst, const 
             double a12[12];
             tensor_factors12(v, a12);
 #pragma unroll
-            for (int q = 0; q < 12; q++) tile[q][ly][lane] = (TA)a12[q];
+            for (int q = 0; q < 12; q++) tile[q][ly][lane] = Sto<TA>::quant(a12[q]);
         }
     }
     __syncthreads();
@@ -215,9 +216,10 @@ k_motion_tensor_rec(Img f1, Img f2, TensorScale hs, TA *__restrict__ dst, const 
         tile_diag<TY>(lane, m, ly, lx);
         const int y = y0 + ly, x = x0 + lx;
         if (y < Y && x < X && !(dbg & 2)) {
-            TA *o = dst + (size_t)sk_index(sk, z, y, x) * 12;
+            Rec<TA, 12> o;
 #pragma unroll
-            for (int q = 0; q < 12; q++) o[q] = tile[q][ly][lx];
+            for (int q = 0; q < 12; q++) o.v[q] = tile[q][ly][lx];
+            strec<TA, 12>(dst, sk_index(sk, z, y, x), o);
         }
     }
 }
@@ -226,7 +228,7 @@ template <typename TA>
 void launch_motion_tensor_rec(hipStream_t st, const float *f1, const float *f2, double hz, double hy, double hx, TA *dst,
                               const Skew &sk)
 {
-    constexpr int TY = sizeof(TA) == 8 ? 16 : 32;  // 12 x TY x 34 values of LDS
+    constexpr int TY = sizeof(typename Sto<TA>::val) == 8 ? 16 : 32;  // 12 x TY x 34 values of LDS
     FR3D_CHECK(sk.Z <= 65535, "motion tensor: z axis longer than 65535");
     Img a{f1, sk.Z, sk.Y, sk.X}, b{f2, sk.Z, sk.Y, sk.X};
     static const char *env = getenv("FR3D_TENSOR_DBG");
@@ -244,6 +246,8 @@ template void launch_motion_tensor_rec<float>(hipStream_t, const float *, const 
                                               const Skew &);
 template void launch_motion_tensor_rec<double>(hipStream_t, const float *, const float *, double, double, double, double *,
                                                const Skew &);
+template void launch_motion_tensor_rec<pk42>(hipStream_t, const float *, const float *, double, double, double, pk42 *,
+                                             const Skew &);
 
 template <typename TA>
 void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int Z, int Y, int X,

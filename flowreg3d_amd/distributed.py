@@ -79,7 +79,18 @@ def _broadcast_packed(payload, scalars, src: int, device: Optional[str], on_devi
     dist.broadcast(flat, src=src)  # <- the path's single data collective (RCCL over xGMI with backend "nccl")
     if on_device and not use_cuda:
         flat = flat.to(_bind_device(device))  # gloo rehearsal of the device-resident path on a GPU box
+    _wait_for_payload(flat)
     return meta, flat, scalars
+
+
+def _wait_for_payload(flat):
+    """RCCL only ENQUEUES the broadcast on torch's communication stream; the engine reads the payload on its
+    own non-blocking HIP stream (engine.hip: hipStreamNonBlocking), which no torch stream orders.  Wait on the
+    host until the buffer is complete before any engine call may see its address (gloo rehearsal: the upload
+    of the received CPU tensor goes through the same wait)."""
+    if flat.is_cuda:
+        import torch
+        torch.cuda.synchronize(flat.device)
 
 
 def _unpack_host(meta, flat):

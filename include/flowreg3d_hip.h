@@ -52,10 +52,13 @@ typedef struct fr3d_params {
                                           2: fp64 storage and arithmetic in the solver (2x the
                                              bytes; for configurations where the reference's own
                                              iteration is ill-conditioned);
+                                          3: packed 42-bit storage (the upper 42 bits of each fp64 value, three
+                                             values per 16 bytes: 31 significant bits for 4/3 of the fp32 bytes),
+                                             fp64 arithmetic; a_smooth == 1 sweep only (mode 2 otherwise);
                                           FR3D_SOLVER_AUTO (-1): the cheapest mode measured to stay within
                                              1e-4 voxels of the reference CPU path -- 1 for one channel up to
-                                             2^25 voxels, 2 for larger volumes and for several channels
-                                             (what the Python mirror passes by default) */
+                                             2^25 voxels, 3 for larger single-channel volumes, 2 for several
+                                             channels (what the Python mirror passes by default) */
     int reserved[7];
 } fr3d_params;
 #define FR3D_SOLVER_AUTO (-1)
@@ -204,6 +207,14 @@ int fr3d_median5(const float *in, int Z, int Y, int X, float *out);
  * sizes: max_out x 3 ints (z,y,x).  Returns the number of solves (>= 1) or -1. */
 int fr3d_schedule(int Z, int Y, int X, double eta, int levels, int min_level, int *sizes,
                   int max_out, int *min_level_eff);
+
+/* Host-only self-check of the SOR launch schedule (k_sor.hip; no GPU needed): replays the kernel's index
+ * arithmetic for a level of Z x Y x X voxels, `iterations` sweeps, psi updates every `update_lag` iterations, tiles of
+ * 64 lanes x `tile_rows` rows x `chain` consecutive iterations per workgroup (0, 0 = the shape the engine uses).
+ * Every voxel update of core/level_solver_3d.py:383-540 must be issued exactly once, by launch i + j + k + 2 t.
+ * Returns the number of violations (0 = consistent), -1 on bad arguments; *n_updates = updates issued. */
+long long fr3d_sor_schedule_check(int Z, int Y, int X, int iterations, int update_lag, int tile_rows, int chain,
+                                  long long *n_updates);
 
 /* ---- device memory helpers (so a host program needs no other GPU runtime) -------------- */
 void *fr3d_dev_malloc(size_t bytes);

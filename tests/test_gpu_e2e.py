@@ -27,7 +27,7 @@ def test_flow_vs_reference_golden(hip, name):
     assert mean < EPE_MEAN_TOL, (mean, mx)
 
 
-@pytest.mark.parametrize("fp64", [False, True])
+@pytest.mark.parametrize("fp64", [False, True, 2, 3])
 def test_flow_vs_oracle_cfg1_full_iterations(hip, oracle, fp64):
     # BASELINE config 1 at the full 100 iterations (the golden uses 20 to keep pure Python affordable)
     from flowreg3d_amd.synthetic import make_pair
@@ -100,3 +100,30 @@ def test_fp64_storage_mode_vs_reference_golden(hip, name, tol):
     mean, mx = _epe(flow, g["flow"])
     print(f"{name} fp64-storage: EPE vs reference mean {mean:.3e} max {mx:.3e}")
     assert mean < tol, (mean, mx)
+
+
+def test_packed42_storage_tracks_fp64_storage(hip):
+    """solver_fp64=3 (three values per 16 bytes, 31 significant bits) must sit between fp32 and fp64 storage: within
+    1e-6 of the fp64-storage flow where fp32 storage is ~1e-5 away (one and two channels, odd sizes so that rows of
+    every length and partly filled tiles occur)."""
+    from flowreg3d_amd.synthetic import make_pair
+    kw = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=60, min_level=0, levels=2, eta=0.8,
+              a_smooth=1.0, a_data=0.45)
+    for shape, ch in (((37, 70, 53), 1), ((33, 41, 66), 2)):
+        fixed, moving, _ = make_pair(shape, seed=21, channels=ch)
+        f64 = hip.get_displacement(fixed, moving, solver_fp64=2, **kw)
+        p42 = hip.get_displacement(fixed, moving, solver_fp64=3, **kw)
+        f32 = hip.get_displacement(fixed, moving, solver_fp64=1, **kw)
+        m42, x42 = _epe(p42, f64)
+        m32, x32 = _epe(f32, f64)
+        print(f"{shape} C={ch}: packed-42 vs fp64 storage mean {m42:.3e} max {x42:.3e}; fp32 storage mean {m32:.3e} max {x32:.3e}")
+        assert m42 < 1e-6 and m42 < 0.1 * m32 + 1e-9, (m42, m32)
+
+
+def test_packed42_falls_back_to_fp64_storage_for_a_smooth(hip):
+    """the psi_smooth solver has no packed form: solver_fp64=3 with a_smooth != 1 runs fp64 storage (bit for bit)."""
+    g = golden("e2e_asmooth")
+    kw = params_of(g)
+    a = hip.get_displacement(g["fixed"], g["moving"], solver_fp64=3, **kw)
+    b = hip.get_displacement(g["fixed"], g["moving"], solver_fp64=2, **kw)
+    assert np.array_equal(a, b)

@@ -2,7 +2,8 @@
 """A/B timing of the SOR sweep under different values of one environment switch that the engine reads per call
 (e.g. FR3D_SOR_LW = 64|32|16, lanes per row segment), interleaved on one box; also checks that every setting gives
 bit-identical flows.
-usage (GPU box): python tools/experiments/sor_env_probe.py EDGE BATCH VAR v1,v2,... [reps]"""
+usage (GPU box): [FR3D_PROBE_MODE=0..3] python tools/experiments/sor_env_probe.py EDGE BATCH VAR v1,v2,... [reps]
+(the switches exist in the experiment build only: FR3D_LIB=flowreg3d_amd/lib/libflowreg3d_hip_exp.so)"""
 import ctypes as C
 import json
 import os
@@ -26,7 +27,8 @@ def main():
     fixed, moving, _ = fast_pair((n, n, n))
     nv = n ** 3
     params = _lib.make_params(alpha=(0.25,) * 3, update_lag=5, iterations=100, min_level=0, levels=levels, eta=0.8,
-                              a_smooth=1.0, a_data=0.45, n_channels=1, solver_fp64=1)
+                              a_smooth=1.0, a_data=0.45, n_channels=1,
+                              solver_fp64=int(os.environ.get("FR3D_PROBE_MODE", "1")))
     ref = lib.fr3d_dev_malloc(nv * 4)
     mov = lib.fr3d_dev_malloc(nv * 4 * nb)
     flows = lib.fr3d_dev_malloc(nv * 12 * nb)
@@ -64,7 +66,7 @@ def main():
             run(True)
             wall = time.perf_counter() - t0
             s = _lib.prof_get()["sor"]
-            print(json.dumps({"edge": n, "batch": nb, var: v, "rep": rep, "sor_ms_per_vol": round(s["ms"] / nb, 2),
+            print(json.dumps({"edge": n, "batch": nb, "mode": int(os.environ.get("FR3D_PROBE_MODE", "1")), var: v, "rep": rep, "sor_ms_per_vol": round(s["ms"] / nb, 2),
                               "frac": round(s["algo_bytes"] / s["ms"] / 8e9, 4), "launches": s["launches"],
                               "wall_ms_per_vol": round(1e3 * wall / nb, 1)}), flush=True)
 
