@@ -93,7 +93,7 @@ SIGNATURES = {
                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, _vp]),
     "fr3d_median5": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_schedule": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, _ip, C.c_int, _ip]),
-    "fr3d_sor_schedule_check": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "fr3d_sor_schedule_check": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.POINTER(C.c_longlong)]),
     "fr3d_dev_malloc": (C.c_void_p, [C.c_size_t]),
     "fr3d_dev_free": (None, [_vp]),
@@ -129,6 +129,8 @@ def load():
                 pass
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("FR3D_LIB") and not hasattr(lib, name):
+                continue  # an older build selected for an A/B run may lack newer entry points
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

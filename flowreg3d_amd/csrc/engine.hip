@@ -220,7 +220,7 @@ struct Engine {
     std::map<std::string, DevBuf> bufs;
     std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
     std::map<std::tuple<int, int, int, int, int>, SorSched> scheds;  // (Z,Y,X,iterations,lag) of a level (a_smooth != 1)
-    std::map<std::tuple<int, int, int, int, int, int, int>, SorChainSched> chain_scheds;  // (Z,Y,X,iterations,update_lag,rows,chain): a_smooth == 1
+    std::map<std::tuple<int, int, int, int, int, int>, SorChainSched> chain_scheds;  // (Z,Y,X,iterations,rows,chain): a_smooth == 1
 
     // device tables of the compact skewed layout per level geometry (fr3d_internal.h: Skew::pb / cp)
     struct Compact {
@@ -260,14 +260,14 @@ struct Engine {
             it = scheds.emplace(key, build_sor_schedule(sk, iterations, 4, lag)).first;
         return it->second;
     }
-    const SorChainSched &chain_sched(const Skew &sk, int iterations, int update_lag)
+    const SorChainSched &chain_sched(const Skew &sk, int iterations)
     {
         int by, nch;
         sor_tile_shape(sk, by, nch);
-        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, update_lag, by, nch);
+        auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, by, nch);
         auto it = chain_scheds.find(key);
         if (it == chain_scheds.end()) {
-            it = chain_scheds.emplace(key, build_sor_chain_schedule(sk, iterations, update_lag, by, nch)).first;
+            it = chain_scheds.emplace(key, build_sor_chain_schedule(sk, iterations, by, nch)).first;
         }
         return it->second;
     }
@@ -593,7 +593,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         a.update_lag = p.update_lag;
         if (p.a_smooth == 1.0) {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
-            long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.chain_sched(sk, p.iterations, p.update_lag));
+            long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.chain_sched(sk, p.iterations));
             // algorithmic traffic of the reference's update: 9C tensor entries + C (w psi) + 3 L + 3 d read, 3 d written,
             // in the solver's storage type: 4 (10C + 9) B with fp32 storage, twice that with fp64 storage, 4/3 of it
             // with packed 42-bit storage
@@ -1624,7 +1624,7 @@ int fr3d_level_solve(const float *A, const float *weight, const float *uvw, int 
     a.update_lag = update_lag;
     if (fast) {
         launch_laplace_rec<float>(e.st, dU, dU + n, dU + 2 * n, sk, a.ax, a.ay, a.az, Lb);
-        launch_sor<float>(e.st, a, solver_fp64 != 0, e.chain_sched(sk, iterations, update_lag));
+        launch_sor<float>(e.st, a, solver_fp64 != 0, e.chain_sched(sk, iterations));
     } else {
         float *smU = (float *)s.alloc(ns * 3 * 4), *smD = (float *)s.alloc(ns * 9 * 4), *smP = (float *)s.alloc(ns * 4);
         SmoothArgs<float> sa;
@@ -1695,16 +1695,15 @@ int fr3d_schedule(int Z, int Y, int X, double eta, int levels, int min_level, in
 
 // ---- memory helpers -----------------------------------------------------------------------------
 
-long long fr3d_sor_schedule_check(int Z, int Y, int X, int iterations, int update_lag, int tile_rows, int chain,
-                                  long long *n_updates)
+long long fr3d_sor_schedule_check(int Z, int Y, int X, int iterations, int tile_rows, int chain, long long *n_updates)
 {
     try {
-        if (Z < 1 || Y < 1 || X < 1 || iterations < 0 || update_lag < 1 || tile_rows < 0 || chain < 0) {
+        if (Z < 1 || Y < 1 || X < 1 || iterations < 0 || tile_rows < 0 || chain < 0) {
             g_err = "bad schedule arguments";
             return -1;
         }
         if (tile_rows == 0 || chain == 0) sor_tile_shape(make_skew(Z, Y, X), tile_rows, chain);
-        return check_chain_schedule(Z, Y, X, iterations, update_lag, tile_rows, chain, n_updates);
+        return check_chain_schedule(Z, Y, X, iterations, tile_rows, chain, n_updates);
     } catch (const std::exception &ex) {
         g_err = ex.what();
         return -1;

@@ -295,11 +295,17 @@ void launch_laplace_rec(hipStream_t st, const float *u, const float *v, const fl
 // Launch schedule of one level geometry: for every launch tau and every in-flight iteration t the
 // bounding box (in tile units) of the valid part of hyperplane s = tau - 2t, so that only tiles that
 // can hold voxels are dispatched (an all-covering grid spends ~8 us per launch on empty workgroups).
-struct SorEntry {
-    int pre;               // tiles of this launch before this group
-    short kb0, njb;        // first k-tile, j-tiles per k-tile row (rows are left-aligned)
-    short toff, nit;       // first iteration of the group relative to the launch's t_lo; iterations in the group
+// 16 bytes of ints: the kernels fetch an entry with ONE scalar load (s_load_dwordx4).  16-bit fields behind the
+// first 8 bytes made the compiler fetch them with vector loads -- two extra memory round trips at the head of every
+// wave, 14 % of the sweep's rate.
+struct alignas(16) SorEntry {
+    int pre;  // tiles of this launch before this group
+    int kb0;  // first k-tile
+    int njb;  // j-tiles per k-tile row (rows are left-aligned)
+    int tn;   // first iteration of the group relative to the launch's t_lo (low 16 bits) | iterations in the group << 16
 };
+__host__ __device__ static inline int sor_entry_toff(const SorEntry &e) { return e.tn & 0xffff; }
+__host__ __device__ static inline int sor_entry_nit(const SorEntry &e) { return e.tn >> 16; }
 #define SOR_LUT_SHIFT 6
 struct SorSched {
     std::vector<int> tau, t_lo, nt, first, ntiles;  // per launch
@@ -319,28 +325,23 @@ struct SorSched {
     int *bnd_meta = nullptr;                         // device, (first, count) per hyperplane
     int bnd_max = 0;                                 // largest bnd_count
 };
-// Schedule of the a_smooth == 1 sweep (k_sor.hip).  Every launch tau has two parts, each its own kernel:
-// part 0 = ordinary iterations, part 1 = psi-update iterations (t % update_lag == 0).  An entry of part 0 is a
-// CHAIN of up to `nch` consecutive ordinary iterations t0 .. t0+n-1: one workgroup (64 lanes x `by` rows x `nch`
+// Schedule of the a_smooth == 1 sweep (k_sor.hip).  An entry is a CHAIN of up to `nch` consecutive iterations
+// t0 .. t0+n-1 (ordinary and psi-update iterations alike; a wave decides which it is): one workgroup (64 lanes x `by` rows x `nch`
 // chain positions) takes the tile (rows k.., lanes jj..) of iteration t0 on plane s0 = tau - 2 t0 and, at chain
 // position n, the rows k-n.. of iteration t0+n on plane s0 - 2n.  Plane s0-2n-1 is the "minus" neighbour plane of
 // position n and the "plus" neighbour plane of position n+1, the same rows and (to within one lane) the same
 // lanes of it: a chain of n iterations fetches n+1 neighbour planes instead of 2n, all of them written by the
 // PREVIOUS launch, so there is nothing to synchronise -- the sharing happens in the CU's L1 and the XCD's L2.
 struct SorChainSched {
-    struct Part {
-        std::vector<int> first, nent, ntiles, lut_first;  // per launch
-    };
-    std::vector<int> tau, t_lo;  // per launch
-    Part part[2];
+    std::vector<int> tau, t_lo, first, nent, ntiles, lut_first;  // per launch
     SorEntry *entries = nullptr;  // device
     int *lut = nullptr;           // device
     int by = 2, nch = 1;
 };
-SorChainSched build_sor_chain_schedule(const Skew &sk, int iterations, int update_lag, int by, int nch);
+SorChainSched build_sor_chain_schedule(const Skew &sk, int iterations, int by, int nch);
 void free_sor_chain_schedule(SorChainSched &s);
 // host replay of the kernel's index arithmetic: 0 = every update issued exactly once in the right launch
-long long check_chain_schedule(int Z, int Y, int X, int iterations, int update_lag, int by, int nch, long long *n_updates);
+long long check_chain_schedule(int Z, int Y, int X, int iterations, int by, int nch, long long *n_updates);
 // workgroup shape of the sweep: rows per tile and chain positions
 void sor_tile_shape(const Skew &sk, int &by, int &nch);
 // iteration t works on hyperplane tau - lag*t in launch tau (lag 2: a_smooth == 1 kernel; lag 4 = SM_LAG:

@@ -33,15 +33,15 @@
 namespace fr3d {
 
 #define SOR_BX 64
-#define SOR_MAX_THREADS 1024  // 64 lanes x rows x chain positions of an ordinary-iteration workgroup
+#define SOR_MAX_THREADS 512  // 64 lanes x rows x chain positions of a workgroup (8 waves: 2 x 4 or 4 x 2)
 
-template <typename R, typename S, int C, bool UPD>
-__global__ void __launch_bounds__(UPD ? 256 : SOR_MAX_THREADS)
+template <typename R, typename S, int C>
+__global__ void __launch_bounds__(SOR_MAX_THREADS)
 k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__restrict__ ent,
            const int *__restrict__ lut)
 {
     const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X;
-    // blockIdx.x enumerates the tiles of all groups of this launch part (schedule built on the host)
+    // blockIdx.x enumerates the tiles of all groups of this launch (schedule built on the host)
     const int vol = blockIdx.y;
     const int b = blockIdx.x;
     // find the group: the table gives the entry of the first tile of this tile group, a short
@@ -54,8 +54,8 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
     // a wave is one row of one chain position (blockDim.x == 64): row and iteration are wave-uniform, which
     // keeps the row starts in SGPRs
     const int n = __builtin_amdgcn_readfirstlane((int)threadIdx.z);
-    if (n >= en.nit) return;
-    const int t = t_lo + en.toff + n;
+    if (n >= sor_entry_nit(en)) return;
+    const int t = t_lo + sor_entry_toff(en) + n;
     const int s = tau - 2 * t;
     const int k = (en.kb0 + local / en.njb) * (int)blockDim.y + __builtin_amdgcn_readfirstlane((int)threadIdx.y) - n;
     if (k < 0 || k >= Z) return;
@@ -92,6 +92,46 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
     const long long yp = j < Y - 1 ? bp + jj + d2 + 1 : c0;
     const long long zm = k > 0 ? bzm + jj : c0;
     const long long zp = k < Z - 1 ? bzp + jj : c0;
+    const bool upd = (t % a.update_lag) == 0;
+    R du1, dv1, dw1;
+#ifdef FR3D_SOR_PHASED
+    constexpr bool phased = FR3D_SOR_PHASED != 0;
+#else
+    // Packed storage: a psi-update wave builds its system first and fetches the neighbours afterwards, an ordinary
+    // wave has all its loads fenced into one group -- 82 instead of 92 VGPRs and 0.550 against 0.513 of the roofline
+    // at 512^3 (same box, profiles/r03/sor_variants_ab.txt).  float / double storage: all loads up front, which
+    // measured the same (fp32 storage) or 3 % better (fp64 storage) than the phase-ordered form.
+    constexpr bool phased = std::is_same<S, pk42>::value;
+#endif
+    if constexpr (phased) {
+    Rec<S, 3> q0 = ldrec<S, 3>(D, c0);
+    Rec<S, 3> qxm, qxp, qym, qyp, qzm, qzp;
+    R m[9];
+    if (upd) {
+        pin(q0);
+        sor_system<R, S, C>(a, true, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, (R)q0.v[0], (R)q0.v[1], (R)q0.v[2], m);
+        qxm = ldrec<S, 3>(D, xm); qxp = ldrec<S, 3>(D, xp);
+        qym = ldrec<S, 3>(D, ym); qyp = ldrec<S, 3>(D, yp);
+        qzm = ldrec<S, 3>(D, zm); qzp = ldrec<S, 3>(D, zp);
+        pin(qxm, qxp, qym, qyp, qzm, qzp);
+    } else {
+        Rec<S, 9> mr = ldrec<S, 9>(a.M + vol * a.vsM, c0);
+        qxm = ldrec<S, 3>(D, xm); qxp = ldrec<S, 3>(D, xp);
+        qym = ldrec<S, 3>(D, ym); qyp = ldrec<S, 3>(D, yp);
+        qzm = ldrec<S, 3>(D, zm); qzp = ldrec<S, 3>(D, zp);
+        pin(q0, mr, qxm, qxp, qym, qyp, qzm, qzp);
+#pragma unroll
+        for (int q = 0; q < 9; q++) m[q] = (R)mr.v[q];
+    }
+    const R du0 = (R)q0.v[0], dv0 = (R)q0.v[1], dw0 = (R)q0.v[2];
+    const R su_x = (R)qxm.v[0] + (R)qxp.v[0], sv_x = (R)qxm.v[1] + (R)qxp.v[1], sw_x = (R)qxm.v[2] + (R)qxp.v[2];
+    const R su_y = (R)qym.v[0] + (R)qyp.v[0], sv_y = (R)qym.v[1] + (R)qyp.v[1], sw_y = (R)qym.v[2] + (R)qyp.v[2];
+    const R su_z = (R)qzm.v[0] + (R)qzp.v[0], sv_z = (R)qzm.v[1] + (R)qzp.v[1], sw_z = (R)qzm.v[2] + (R)qzp.v[2];
+    sor_relax_sel<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,
+                     dw1);
+    } else {
+    // All seven increment records are requested before anything else; a psi-update wave adds its factor loads
+    // behind them.
     const Rec<S, 3> q0 = ldrec<S, 3>(D, c0);
     const Rec<S, 3> qxm = ldrec<S, 3>(D, xm), qxp = ldrec<S, 3>(D, xp);
     const Rec<S, 3> qym = ldrec<S, 3>(D, ym), qyp = ldrec<S, 3>(D, yp);
@@ -101,10 +141,10 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
     const R su_y = (R)qym.v[0] + (R)qyp.v[0], sv_y = (R)qym.v[1] + (R)qyp.v[1], sw_y = (R)qym.v[2] + (R)qyp.v[2];
     const R su_z = (R)qzm.v[0] + (R)qzp.v[0], sv_z = (R)qzm.v[1] + (R)qzp.v[1], sw_z = (R)qzm.v[2] + (R)qzp.v[2];
     R m[9];
-    sor_system<R, S, C, UPD>(a, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
-    R du1, dv1, dw1;
+    sor_system<R, S, C>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
     sor_relax<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,
                  dw1);
+    }
     Rec<S, 3> out;
     out.v[0] = Sto<S>::quant(du1);
     out.v[1] = Sto<S>::quant(dv1);
@@ -119,36 +159,29 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
 }
 
 template <typename R, typename S>
-static void launch_part(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo, const SorChainSched &sc, size_t l, int part)
+static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo, const SorChainSched &sc, size_t l)
 {
-    const SorChainSched::Part &P = sc.part[part];
-    const int ntiles = P.ntiles[l];
+    const int ntiles = sc.ntiles[l];
     if (ntiles <= 0) return;
-    const SorEntry *ent = sc.entries + P.first[l];
-    const int *lut = sc.lut + P.lut_first[l];
-    const int nent = P.nent[l];
-    dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1);
-    if (part == 0) {
-        // ordinary iterations stream the frozen 3x3 system: one instantiation for every channel count
-        hipLaunchKernelGGL((k_sor_step<R, S, 1, false>), grid, dim3(SOR_BX, sc.by, sc.nch), 0, st, a, tau, t_lo, nent, ent, lut);
-    } else {
-        const dim3 block(SOR_BX, sc.by, 1);
+    const SorEntry *ent = sc.entries + sc.first[l];
+    const int *lut = sc.lut + sc.lut_first[l];
+    const int nent = sc.nent[l];
+    const dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, sc.by, sc.nch);
 #define FR3D_SOR_CASE(CH)                                                                                     \
-    case CH: hipLaunchKernelGGL((k_sor_step<R, S, CH, true>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut); break;
-        switch (a.C) {
-            FR3D_SOR_CASE(1)
-            FR3D_SOR_CASE(2)
-            FR3D_SOR_CASE(3)
-            FR3D_SOR_CASE(4)
-            // 5..FR3D_MAX_CHANNELS channels: one instantiation with the channel loop bound read at run time
-            // (the loop already handles one channel at a time, k_sor_core.h; level_solver_3d.py:356-377 loops over any C)
-            default:
-                FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
-                hipLaunchKernelGGL((k_sor_step<R, S, 0, true>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut);
-                break;
-        }
-#undef FR3D_SOR_CASE
+    case CH: hipLaunchKernelGGL((k_sor_step<R, S, CH>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut); break;
+    switch (a.C) {
+        FR3D_SOR_CASE(1)
+        FR3D_SOR_CASE(2)
+        FR3D_SOR_CASE(3)
+        FR3D_SOR_CASE(4)
+        // 5..FR3D_MAX_CHANNELS channels: one instantiation with the channel loop bound read at run time
+        // (the loop already handles one channel at a time, k_sor_core.h; level_solver_3d.py:356-377 loops over any C)
+        default:
+            FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
+            hipLaunchKernelGGL((k_sor_step<R, S, 0>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut);
+            break;
     }
+#undef FR3D_SOR_CASE
     FR3D_LAUNCH_CHECK();
 }
 
@@ -156,7 +189,7 @@ void sor_tile_shape(const Skew &sk, int &by, int &nch)
 {
     (void)sk;
     by = 2;   // 64 lanes x 2 rows
-    nch = 4;  // x 4 chain positions (update_lag - 1 = 4 ordinary iterations between psi updates with the defaults)
+    nch = 1;  // chain positions: see DESIGN.md section 4 (chains cut the fetched bytes by 9 % and lost 10 % of the rate)
 #ifdef FR3D_EXPERIMENTS
     if (const char *env = getenv("FR3D_SOR_SHAPE")) {  // "<rows>x<chain>", e.g. 2x4
         int b = 0, c = 0;
@@ -188,15 +221,15 @@ static inline int plane_maxlen(const Skew &sk, int s, int klo, int khi)
     return maxlen;
 }
 
-// host side of the schedule: entries and group tables of every launch part (no device calls)
-void make_chain_entries(const Skew &sk, int T, int lagU, int by, int nch, SorChainSched &sc, std::vector<SorEntry> &ent,
+// host side of the schedule: entries and group tables of every launch (no device calls)
+void make_chain_entries(const Skew &sk, int T, int by, int nch, SorChainSched &sc, std::vector<SorEntry> &ent,
                         std::vector<int> &lut)
 {
     sc.by = by;
     sc.nch = nch;
     if (T <= 0) return;
     FR3D_CHECK(T <= 32767, "SOR schedule: more than 32767 iterations");
-    FR3D_CHECK(lagU >= 1 && by >= 1 && nch >= 1 && SOR_BX * by * nch <= SOR_MAX_THREADS, "SOR schedule: bad tile shape");
+    FR3D_CHECK(by >= 1 && nch >= 1 && SOR_BX * by * nch <= SOR_MAX_THREADS, "SOR schedule: bad tile shape");
     const int S = sk.S;
     const int last = (S - 1) + 2 * (T - 1);
     for (int tau = 0; tau <= last; tau++) {
@@ -207,62 +240,53 @@ void make_chain_entries(const Skew &sk, int T, int lagU, int by, int nch, SorCha
         if (t_lo > t_hi) continue;
         sc.tau.push_back(tau);
         sc.t_lo.push_back(t_lo);
-        for (int part = 0; part < 2; part++) {
-            SorChainSched::Part &P = sc.part[part];
-            P.first.push_back((int)ent.size());
-            int pre = 0, nent = 0;
-            int t = t_lo;
-            while (t <= t_hi) {
-                const bool psi = (t % lagU) == 0;
-                if (psi != (part == 1)) { t++; continue; }
-                // the group: one psi iteration, or a run of up to nch consecutive ordinary iterations
-                int n = 1;
-                if (part == 0)
-                    while (n < nch && t + n <= t_hi && ((t + n) % lagU) != 0) n++;
-                // tile rows in the coordinates of chain position 0: position q handles row k - q of plane s0 - 2q
-                int kmin = INT_MAX, kmax = INT_MIN, maxlen = 0;
-                for (int q = 0; q < n; q++) {
-                    int klo, khi;
-                    const int s = tau - 2 * (t + q);
-                    if (!plane_rows(sk, s, klo, khi)) continue;
-                    kmin = std::min(kmin, klo + q);
-                    kmax = std::max(kmax, khi + q);
-                    maxlen = std::max(maxlen, plane_maxlen(sk, s, klo, khi));
-                }
-                if (maxlen > 0) {
-                    SorEntry e;
-                    e.pre = pre;
-                    e.kb0 = (short)(kmin / by);
-                    e.njb = (short)cdiv(maxlen, SOR_BX);
-                    e.toff = (short)(t - t_lo);
-                    e.nit = (short)n;
-                    pre += (kmax / by - kmin / by + 1) * e.njb;
-                    ent.push_back(e);
-                    nent++;
-                }
-                t += n;
+        sc.first.push_back((int)ent.size());
+        int pre = 0, nent = 0;
+        for (int t = t_lo; t <= t_hi;) {
+            // the group: a run of up to nch consecutive iterations
+            const int n = std::min(nch, t_hi - t + 1);
+            // tile rows in the coordinates of chain position 0: position q handles row k - q of plane s0 - 2q
+            int kmin = INT_MAX, kmax = INT_MIN, maxlen = 0;
+            for (int q = 0; q < n; q++) {
+                int klo, khi;
+                const int s = tau - 2 * (t + q);
+                if (!plane_rows(sk, s, klo, khi)) continue;
+                kmin = std::min(kmin, klo + q);
+                kmax = std::max(kmax, khi + q);
+                maxlen = std::max(maxlen, plane_maxlen(sk, s, klo, khi));
             }
-            P.nent.push_back(nent);
-            P.ntiles.push_back(pre);
-            // group table of this launch part
-            P.lut_first.push_back((int)lut.size());
-            const size_t e0 = (size_t)P.first.back();
-            int cur = 0;
-            for (int g = 0; (g << SOR_LUT_SHIFT) < pre; g++) {
-                const int b0 = g << SOR_LUT_SHIFT;
-                while (cur + 1 < nent && ent[e0 + cur + 1].pre <= b0) cur++;
-                lut.push_back(cur);
+            if (maxlen > 0) {
+                SorEntry e;
+                e.pre = pre;
+                e.kb0 = kmin / by;
+                e.njb = cdiv(maxlen, SOR_BX);
+                e.tn = (t - t_lo) | (n << 16);
+                pre += (kmax / by - kmin / by + 1) * e.njb;
+                ent.push_back(e);
+                nent++;
             }
+            t += n;
+        }
+        sc.nent.push_back(nent);
+        sc.ntiles.push_back(pre);
+        // group table of this launch
+        sc.lut_first.push_back((int)lut.size());
+        const size_t e0 = (size_t)sc.first.back();
+        int cur = 0;
+        for (int g = 0; (g << SOR_LUT_SHIFT) < pre; g++) {
+            const int b0 = g << SOR_LUT_SHIFT;
+            while (cur + 1 < nent && ent[e0 + cur + 1].pre <= b0) cur++;
+            lut.push_back(cur);
         }
     }
 }
 
-SorChainSched build_sor_chain_schedule(const Skew &sk, int T, int lagU, int by, int nch)
+SorChainSched build_sor_chain_schedule(const Skew &sk, int T, int by, int nch)
 {
     SorChainSched sc;
     std::vector<SorEntry> ent;
     std::vector<int> lut;
-    make_chain_entries(sk, T, lagU, by, nch, sc, ent, lut);
+    make_chain_entries(sk, T, by, nch, sc, ent, lut);
     if (T <= 0) return sc;
     FR3D_HIP(hipMalloc((void **)&sc.entries, std::max<size_t>(ent.size(), 1) * sizeof(SorEntry)));
     FR3D_HIP(hipMemcpy(sc.entries, ent.data(), ent.size() * sizeof(SorEntry), hipMemcpyHostToDevice));
@@ -272,54 +296,50 @@ SorChainSched build_sor_chain_schedule(const Skew &sk, int T, int lagU, int by, 
 }
 
 // Host replay of the kernel's index arithmetic over a whole schedule (no device involved): every voxel update
-// (t, k, j, i) must be issued exactly once, by the launch tau = i + j + k + 2t, in the part that matches the kind
-// of iteration t.  Returns 0 and the number of updates, or the number of violations.
-long long check_chain_schedule(int Z, int Y, int X, int T, int lagU, int by, int nch, long long *n_updates)
+// (t, k, j, i) must be issued exactly once, by the launch tau = i + j + k + 2t.  Returns the number of violations
+// (0 = consistent) and the number of updates issued.
+long long check_chain_schedule(int Z, int Y, int X, int T, int by, int nch, long long *n_updates)
 {
     const Skew sk = make_skew(Z, Y, X);
     SorChainSched sc;
     std::vector<SorEntry> ent;
     std::vector<int> lut;
-    make_chain_entries(sk, T, lagU, by, nch, sc, ent, lut);
+    make_chain_entries(sk, T, by, nch, sc, ent, lut);
     const size_t nv = (size_t)Z * Y * X;
     std::vector<unsigned char> seen((size_t)std::max(T, 0) * nv, 0);
     long long bad = 0, total = 0;
     for (size_t l = 0; l < sc.tau.size(); l++) {
-        for (int part = 0; part < 2; part++) {
-            const SorChainSched::Part &P = sc.part[part];
-            const SorEntry *en_ = ent.data() + P.first[l];
-            const int *lu = lut.data() + P.lut_first[l];
-            const int nent = P.nent[l], tau = sc.tau[l], t_lo = sc.t_lo[l];
-            const int nz = part == 0 ? nch : 1;
-            for (int b = 0; b < P.ntiles[l]; b++) {
-                int lo = lu[b >> SOR_LUT_SHIFT];
-                while (lo + 1 < nent && en_[lo + 1].pre <= b) lo++;
-                const SorEntry en = en_[lo];
-                const int local = b - en.pre;
-                if (local < 0) { bad++; continue; }
-                for (int n = 0; n < nz; n++)
-                    for (int ty = 0; ty < by; ty++) {
-                        if (n >= en.nit) continue;
-                        const int t = t_lo + en.toff + n;
-                        if (t < 0 || t >= T || ((t % lagU) == 0) != (part == 1)) { bad++; continue; }
-                        const int s = tau - 2 * t;
-                        const int k = (en.kb0 + local / en.njb) * by + ty - n;
-                        if (k < 0 || k >= Z) continue;
-                        const int r = s - k;
-                        if (r < 0 || r > X + Y - 2) continue;
-                        const int jm0 = sk_jm(X, r);
-                        for (int lane = 0; lane < SOR_BX; lane++) {
-                            const int jj = (local % en.njb) * SOR_BX + lane;
-                            const int j = jj + jm0, i = r - j;
-                            if (j >= Y || i < 0) continue;
-                            if (i >= X) { bad++; continue; }
-                            unsigned char &c = seen[(size_t)t * nv + ((size_t)k * Y + j) * X + i];
-                            if (c) bad++;
-                            c = 1;
-                            total++;
-                        }
+        const SorEntry *en_ = ent.data() + sc.first[l];
+        const int *lu = lut.data() + sc.lut_first[l];
+        const int nent = sc.nent[l], tau = sc.tau[l], t_lo = sc.t_lo[l];
+        for (int b = 0; b < sc.ntiles[l]; b++) {
+            int lo = lu[b >> SOR_LUT_SHIFT];
+            while (lo + 1 < nent && en_[lo + 1].pre <= b) lo++;
+            const SorEntry en = en_[lo];
+            const int local = b - en.pre;
+            if (local < 0) { bad++; continue; }
+            for (int n = 0; n < nch; n++)
+                for (int ty = 0; ty < by; ty++) {
+                    if (n >= sor_entry_nit(en)) continue;
+                    const int t = t_lo + sor_entry_toff(en) + n;
+                    if (t < 0 || t >= T) { bad++; continue; }
+                    const int s = tau - 2 * t;
+                    const int k = (en.kb0 + local / en.njb) * by + ty - n;
+                    if (k < 0 || k >= Z) continue;
+                    const int r = s - k;
+                    if (r < 0 || r > X + Y - 2) continue;
+                    const int jm0 = sk_jm(X, r);
+                    for (int lane = 0; lane < SOR_BX; lane++) {
+                        const int jj = (local % en.njb) * SOR_BX + lane;
+                        const int j = jj + jm0, i = r - j;
+                        if (j >= Y || i < 0) continue;
+                        if (i >= X) { bad++; continue; }
+                        unsigned char &c = seen[(size_t)t * nv + ((size_t)k * Y + j) * X + i];
+                        if (c) bad++;
+                        c = 1;
+                        total++;
                     }
-            }
+                }
         }
     }
     for (unsigned char c : seen) bad += c ? 0 : 1;
@@ -366,8 +386,7 @@ SorSched build_sor_schedule(const Skew &sk, int T, int by, int lag)
             const int klo = std::max(0, s - (X - 1) - (Y - 1)), khi = std::min(Z - 1, s);
             SorEntry e;
             e.pre = pre;
-            e.toff = (short)(t - t_lo);
-            e.nit = 1;
+            e.tn = (t - t_lo) | (1 << 16);
             e.kb0 = 0;
             e.njb = 1;
             if (klo <= khi) {
@@ -379,8 +398,8 @@ SorSched build_sor_schedule(const Skew &sk, int T, int by, int lag)
                 }
                 if (maxlen > 0) {
                     const int kb0 = klo / by, kb1 = khi / by;
-                    e.kb0 = (short)kb0;
-                    e.njb = (short)cdiv(maxlen, SOR_BX);
+                    e.kb0 = kb0;
+                    e.njb = cdiv(maxlen, SOR_BX);
                     pre += (kb1 - kb0 + 1) * e.njb;
                 }
             }
@@ -457,16 +476,14 @@ long long launch_sor(hipStream_t st, const SorArgsT<S> &a_in, bool fp64, const S
 #endif
     long long launches = 0;
     for (size_t l = 0; l < sc.tau.size(); l++) {
-        for (int part = 0; part < 2; part++) {
-            if (sc.part[part].ntiles[l] <= 0) continue;
-            if constexpr (Sto<S>::wide) {
-                launch_part<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc, l, part);
-            } else {
-                if (fp64) launch_part<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc, l, part);
-                else launch_part<float, S>(st, a, sc.tau[l], sc.t_lo[l], sc, l, part);
-            }
-            launches++;
+        if (sc.ntiles[l] <= 0) continue;
+        if constexpr (Sto<S>::wide) {
+            launch_step<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc, l);
+        } else {
+            if (fp64) launch_step<double, S>(st, a, sc.tau[l], sc.t_lo[l], sc, l);
+            else launch_step<float, S>(st, a, sc.tau[l], sc.t_lo[l], sc, l);
         }
+        launches++;
     }
     return launches;
 }

@@ -106,19 +106,16 @@ __device__ __forceinline__ void strec(S *base, long long voxel, const Rec<S, N> 
 
 // The 3x3 system of one voxel for the current psi window: m[0..5] = M11,M22,M33,M12,M13,M23 with
 // M = sum_c w_c psi_c J_c, m[6..8] = b = L - sum_c w_c psi_c (J14,J24,J34)_c.  psi is frozen between
-// psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration (UPD)
+// psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration (`upd`)
 // builds them from the square-root factors and, when `store`, writes them; the other iterations
 // stream the 9 stored values -- independent of the channel count.  `e` is the voxel's index inside one
 // volume's arrays, vM/vA/vL the (wave-uniform) element offsets of the volume's slab.
-// UPD is a template argument: the two kinds of iteration are separate kernels, because the psi branch keeps up
-// to 158 VGPRs live (fp64 storage, several channels) where an ordinary iteration needs 55-80 -- in one kernel the
-// ordinary iterations (4 of 5) would run at the psi branch's occupancy.
-template <typename R, typename S, int C, bool UPD>
-__device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool store, long long vM, long long vA,
+template <typename R, typename S, int C>
+__device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool store, long long vM, long long vA,
                                            long long vL, long long e, R du0, R dv0, R dw0, R (&m)[9])
 {
     using V = typename Sto<S>::val;
-    if constexpr (UPD) {
+    if (upd) {
         R M11 = 0, M22 = 0, M33 = 0, M12 = 0, M13 = 0, M23 = 0, bu = 0, bv = 0, bw = 0;
         // one channel at a time: unrolling over channels keeps 12C factors live
         const int nch = C > 0 ? C : a.C;  // C == 0: channel count at run time (5..FR3D_MAX_CHANNELS channels)
@@ -215,6 +212,59 @@ __device__ __forceinline__ void sor_relax(const R (&m)[9], double axd, double ay
     dv1 = fma_<R>(om, (den_v != (R)0 ? n2 / den_v : (R)0), om1 * dv0);
     n2 = num_w - fma_<R>(m[5], dv1, m[4] * du1);
     dw1 = fma_<R>(om, (den_w != (R)0 ? n2 / den_w : (R)0), om1 * dw0);
+}
+
+
+// ---- phase-ordered form of the sweep's loads (k_sor.hip, used with packed storage): a psi-update wave builds its
+// system BEFORE the neighbour loads are issued, fences keep the groups of loads together ----
+// pin(): the empty asm "uses" every value of the records, so the loads that produce them are issued (and waited
+// for) before this point and cannot be sunk into later conditional code; ONE statement per group, because the
+// scheduler may move an independent load below a fence it does not feed (at most 30 operands).
+template <typename S>
+__device__ __forceinline__ void pin(Rec<S, 3> &a)
+{
+    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]));
+}
+template <typename S>
+__device__ __forceinline__ void pin(Rec<S, 3> &a, Rec<S, 3> &b, Rec<S, 3> &c, Rec<S, 3> &d, Rec<S, 3> &e, Rec<S, 3> &f)
+{
+    asm volatile("" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(c.v[0]),
+                 "+v"(c.v[1]), "+v"(c.v[2]), "+v"(d.v[0]), "+v"(d.v[1]), "+v"(d.v[2]), "+v"(e.v[0]), "+v"(e.v[1]),
+                 "+v"(e.v[2]), "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]));
+}
+template <typename S>
+__device__ __forceinline__ void pin(Rec<S, 3> &q, Rec<S, 9> &m, Rec<S, 3> &a, Rec<S, 3> &b, Rec<S, 3> &c, Rec<S, 3> &d,
+                                    Rec<S, 3> &e, Rec<S, 3> &f)
+{
+    asm volatile("" : "+v"(q.v[0]), "+v"(q.v[1]), "+v"(q.v[2]), "+v"(m.v[0]), "+v"(m.v[1]), "+v"(m.v[2]), "+v"(m.v[3]),
+                 "+v"(m.v[4]), "+v"(m.v[5]), "+v"(m.v[6]), "+v"(m.v[7]), "+v"(m.v[8]), "+v"(a.v[0]), "+v"(a.v[1]),
+                 "+v"(a.v[2]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(c.v[0]), "+v"(c.v[1]), "+v"(c.v[2]),
+                 "+v"(d.v[0]), "+v"(d.v[1]), "+v"(d.v[2]), "+v"(e.v[0]), "+v"(e.v[1]), "+v"(e.v[2]), "+v"(f.v[0]),
+                 "+v"(f.v[1]), "+v"(f.v[2]));
+}
+// sor_relax with the quotients formed unconditionally and selected afterwards (den == 0 never occurs with
+// alpha > 0; same values): no branch for the compiler to sink a neighbour load into
+template <typename R>
+__device__ __forceinline__ void sor_relax_sel(const R (&m)[9], double axd, double ayd, double azd, R su_x, R sv_x,
+                                              R sw_x, R su_y, R sv_y, R sw_y, R su_z, R sv_z, R sw_z, R du0, R dv0,
+                                              R dw0, R &du1, R &dv1, R &dw1)
+{
+    const R ax = (R)axd, ay = (R)ayd, az = (R)azd;
+    const R num_u = fma_<R>(az, su_z, fma_<R>(ay, su_y, fma_<R>(ax, su_x, m[6])));
+    const R num_v = fma_<R>(az, sv_z, fma_<R>(ay, sv_y, fma_<R>(ax, sv_x, m[7])));
+    const R num_w = fma_<R>(az, sw_z, fma_<R>(ay, sw_y, fma_<R>(ax, sw_x, m[8])));
+    const R diag = (R)(2.0 * axd + 2.0 * ayd + 2.0 * azd);
+    const R den_u = diag + m[0], den_v = diag + m[1], den_w = diag + m[2];
+    const R om = (R)SOR_OMEGA, om1 = (R)(1.0 - SOR_OMEGA);
+    R n2 = num_u - fma_<R>(m[4], dw0, m[3] * dv0);
+    R q = n2 / den_u;
+    du1 = fma_<R>(om, (den_u != (R)0 ? q : (R)0), om1 * du0);
+    n2 = num_v - fma_<R>(m[5], dw0, m[3] * du1);
+    q = n2 / den_v;
+    dv1 = fma_<R>(om, (den_v != (R)0 ? q : (R)0), om1 * dv0);
+    n2 = num_w - fma_<R>(m[5], dv1, m[4] * du1);
+    q = n2 / den_w;
+    dw1 = fma_<R>(om, (den_w != (R)0 ? q : (R)0), om1 * dw0);
 }
 
 }  // namespace fr3d

@@ -209,12 +209,11 @@ int fr3d_schedule(int Z, int Y, int X, double eta, int levels, int min_level, in
                   int max_out, int *min_level_eff);
 
 /* Host-only self-check of the SOR launch schedule (k_sor.hip; no GPU needed): replays the kernel's index
- * arithmetic for a level of Z x Y x X voxels, `iterations` sweeps, psi updates every `update_lag` iterations, tiles of
- * 64 lanes x `tile_rows` rows x `chain` consecutive iterations per workgroup (0, 0 = the shape the engine uses).
- * Every voxel update of core/level_solver_3d.py:383-540 must be issued exactly once, by launch i + j + k + 2 t.
+ * arithmetic for a level of Z x Y x X voxels and `iterations` sweeps with tiles of 64 lanes x `tile_rows` rows x
+ * `chain` consecutive iterations per workgroup (0, 0 = the shape the engine uses).  Every voxel update of
+ * core/level_solver_3d.py:383-540 must be issued exactly once, by launch i + j + k + 2 t.
  * Returns the number of violations (0 = consistent), -1 on bad arguments; *n_updates = updates issued. */
-long long fr3d_sor_schedule_check(int Z, int Y, int X, int iterations, int update_lag, int tile_rows, int chain,
-                                  long long *n_updates);
+long long fr3d_sor_schedule_check(int Z, int Y, int X, int iterations, int tile_rows, int chain, long long *n_updates);
 
 /* ---- device memory helpers (so a host program needs no other GPU runtime) -------------- */
 void *fr3d_dev_malloc(size_t bytes);

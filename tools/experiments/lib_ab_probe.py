@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of two builds of the engine (FR3D_LIB selects the shared library; one process per build, alternated):
 SOR time per volume and the whole step; LIB may carry one environment setting as path.so@VAR=value.
-usage (GPU box): python tools/experiments/lib_ab_probe.py EDGE BATCH LIB_A LIB_B [reps]"""
+usage (GPU box): [FR3D_PROBE_MODE=0..3] python tools/experiments/lib_ab_probe.py EDGE BATCH REPS LIB_A LIB_B [LIB_C ...]"""
 import json
 import os
 import subprocess
@@ -20,7 +20,8 @@ levels = {64: 2, 128: 3, 256: 4, 512: 5}[n]
 fixed, moving, _ = fast_pair((n, n, n))
 nv = n ** 3
 params = _lib.make_params(alpha=(0.25,) * 3, update_lag=5, iterations=100, min_level=0, levels=levels, eta=0.8,
-                          a_smooth=1.0, a_data=0.45, n_channels=1, solver_fp64=1)
+                          a_smooth=1.0, a_data=0.45, n_channels=1,
+                          solver_fp64=int(os.environ.get("FR3D_PROBE_MODE", "1")))
 ref = lib.fr3d_dev_malloc(nv * 4); mov = lib.fr3d_dev_malloc(nv * 4 * nb)
 flows = lib.fr3d_dev_malloc(nv * 12 * nb); regs = lib.fr3d_dev_malloc(nv * 4 * nb)
 lib.fr3d_h2d(ref, fixed.ctypes.data, nv * 4)
@@ -53,10 +54,10 @@ print(json.dumps(best))
 
 
 def main():
-    n, nb, la, lb = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
-    reps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+    n, nb, reps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    specs = sys.argv[4:]
     for rep in range(reps):
-        for tag, spec in (("A", la), ("B", lb)):
+        for tag, spec in zip("ABCDEFGH", specs):
             lib, _, setting = spec.partition("@")  # "path/to/lib.so@VAR=value" sets VAR for that side
             env = dict(os.environ, FR3D_LIB=os.path.abspath(lib))
             if setting:
@@ -64,7 +65,7 @@ def main():
                 env[k] = v
             r = subprocess.run([sys.executable, "-c", CHILD, n, nb], env=env, capture_output=True, text=True, timeout=600)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            print(json.dumps({"edge": int(n), "batch": int(nb), "lib": tag + ":" + os.path.basename(spec), "rep": rep,
+            print(json.dumps({"edge": int(n), "batch": int(nb), "mode": int(os.environ.get("FR3D_PROBE_MODE", "1")), "lib": tag + ":" + os.path.basename(spec), "rep": rep,
                               **(json.loads(line[-1]) if line else {"error": r.stderr[-300:]})}), flush=True)
 
 
