@@ -1,7 +1,10 @@
 """-m gpu: the batch driver -- preprocessing, w_init bootstrap and propagation,
-executor, statistics -- against the same driver restated on the CPU oracle."""
+executor, statistics -- against the outputs of the REFERENCE's own compensate_arr_3D (tests/golden/drv_*.npz) and,
+for a larger series, against the driver loop restated on the CPU oracle (pinned to the same fixtures on the CPU)."""
 import numpy as np
 import pytest
+
+from driver_cases import CASES, check_against_reference, load_case, oracle_driver
 
 pytestmark = pytest.mark.gpu
 
@@ -16,55 +19,52 @@ def _video(T=6, shape=(10, 16, 18), C=1):
     return (v * 1000 + 100).astype(np.float32), (fixed * 1000 + 100).astype(np.float32)
 
 
-def _oracle_driver(oracle, video, reference, opt):
-    """BatchMotionCorrector.run (compensate_recording_3D.py:431-555) on the oracle."""
-    from flowreg3d_amd.pipeline import _alpha3, _weight_at
-    ref_raw = reference.astype(np.float64)
-    Z, Y, X, nc = ref_raw.shape
-    weight = np.ones((Z, Y, X, nc))
-    for c in range(nc):
-        weight[..., c] = _weight_at(opt.weight, c, nc)
-    pre = lambda fr, ref=None: oracle.apply_gaussian_filter(
-        oracle.normalize(fr, ref=ref, channel_normalization=opt.channel_normalization), np.asarray(opt.sigma))
-    ref_proc = pre(ref_raw)
-    fp = dict(alpha=_alpha3(opt.alpha), weight=weight, levels=opt.levels, min_level=opt.effective_min_level,
-              eta=opt.eta, update_lag=opt.update_lag, iterations=opt.iterations, a_smooth=opt.a_smooth, a_data=opt.a_data)
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("mode", ["parity", "default"])
+def test_compensate_arr_matches_reference_compensate_arr(hip, name, mode):
+    """pipeline.compensate_arr_3D against the REFERENCE's own compensate_arr_3D outputs (tests/golden/drv_*.npz,
+    tools/gen_driver_golden.py; sequential executor): serial and executor bootstrap of w_init, w_init rolled across
+    batches, update_initialization_w=False, two channels with 1-D weights, uint16 series with output_typename, the
+    4-D squeeze path, linear interpolation.  "parity" = fp64 solver storage at the reference's cross-executor
+    tolerance (rtol 1e-5 / atol 1e-6 on `registered`); "default" = the library's automatic solver mode at the
+    north-star flow bound."""
+    import dataclasses
+    from flowreg3d_amd.pipeline import compensate_arr_3D
+    g, meta, opt = load_case(name)
+    if mode == "parity":
+        opt = dataclasses.replace(opt, solver_fp64=2)
+    seen = []
+    reg, w, stats = compensate_arr_3D(g["video"], g["reference"], opt, progress_callback=lambda a, b: seen.append((a, b)),
+                                      return_stats=True)
+    T = g["w"].shape[0]
+    assert seen[-1] == (T, T) and [a for a, _ in seen] == sorted(a for a, _ in seen)
+    assert list(g["progress"][-1]) == [T, T]
+    check_against_reference(g, reg, w, stats, None, 1e-5 if mode == "parity" else 1e-4, f"{name}/{mode}",
+                            parity_grade=mode == "parity")
 
-    def process(batch, batch_proc, w_init):
-        reg = np.empty_like(batch)
-        fl = np.empty(batch.shape[:4] + (3,), np.float32)
-        for t in range(batch.shape[0]):
-            f = oracle.get_displacement(ref_proc, batch_proc[t], uvw=w_init.copy(), **fp).astype(np.float32)
-            reg[t] = oracle.imregister_wrapper(batch[t], f[..., 0], f[..., 1], f[..., 2], ref_raw,
-                                               opt.interpolation_method).reshape(reg[t].shape)
-            fl[t] = f
-        return reg, fl
 
-    regs, flows, stats = [], [], dict(mean_disp=[], max_disp=[], mean_div=[], mean_translation=[])
-    w_init = None
-    for bi, t0 in enumerate(range(0, video.shape[0], opt.buffer_size)):
-        batch = video[t0:t0 + opt.buffer_size]
-        bp = pre(batch, ref_raw)
-        if bi == 0:
-            n_init = min(22, batch.shape[0])
-            _, w0 = process(batch[:n_init], bp[:n_init], np.zeros((Z, Y, X, 3)))
-            w_init = np.mean(w0, axis=0)
-        reg, w = process(batch, bp, w_init)
-        w_init = np.mean(w[-20:], axis=0) if w.shape[0] > 20 else np.mean(w, axis=0)
-        mag = np.sqrt(w[..., 0] ** 2 + w[..., 1] ** 2 + w[..., 2] ** 2)
-        stats["mean_disp"] += np.mean(mag, axis=(1, 2, 3)).tolist()
-        stats["max_disp"] += np.max(mag, axis=(1, 2, 3)).tolist()
-        for t in range(w.shape[0]):
-            div = np.gradient(w[t, ..., 0], axis=2) + np.gradient(w[t, ..., 1], axis=1) + np.gradient(w[t, ..., 2], axis=0)
-            stats["mean_div"].append(float(np.mean(div)))
-            stats["mean_translation"].append(float(np.sqrt(np.mean(w[t, ..., 0]) ** 2 + np.mean(w[t, ..., 1]) ** 2
-                                                           + np.mean(w[t, ..., 2]) ** 2)))
-        regs.append(reg)
-        flows.append(w)
-    return np.concatenate(regs), np.concatenate(flows), stats
+@pytest.mark.parametrize("name", ["drv_t7_b5", "drv_t7_b3", "drv_noinit", "drv_c2_u16"])
+def test_device_sink_driver_matches_reference_compensate_arr(hip, name):
+    """the device-resident driver (run(..., sink="device"): series, flows, w_init means and statistics stay in HBM)
+    against the same reference outputs, fp64 solver storage."""
+    import dataclasses
+    from driver_cases import OUT_DTYPES
+    from flowreg3d_amd.pipeline import BatchMotionCorrectorHip
+    g, meta, opt = load_case(name)
+    bc = BatchMotionCorrectorHip(dataclasses.replace(opt, solver_fp64=2))
+    sink = bc.run(g["video"], g["reference"], sink="device")
+    try:
+        reg, w = sink.registered(), sink.flows()
+    finally:
+        sink.free()
+    if opt.output_typename in OUT_DTYPES:
+        reg = reg.astype(OUT_DTYPES[opt.output_typename])
+    check_against_reference(g, reg, w, bc.stats, bc.w_init, 1e-5, f"{name}/device sink")
 
 
 def test_compensate_arr_matches_oracle_driver(hip, oracle):
+    """a larger series than the reference fixtures afford (pure-Python reference: ~10 us per voxel update), against
+    the oracle-driven loop that tests/test_driver_golden_cpu.py pins to the reference"""
     from flowreg3d_amd.pipeline import Options, compensate_arr_3D
     video, ref = _video()
     opt = Options(min_level=0, levels=3, iterations=12, update_lag=4, buffer_size=4, output_typename=None,
@@ -74,7 +74,7 @@ def test_compensate_arr_matches_oracle_driver(hip, oracle):
                                       return_stats=True)
     assert reg.shape == video.shape and reg.dtype == video.dtype and w.shape == video.shape[:4] + (3,)
     assert seen[-1] == (video.shape[0], video.shape[0]) and [a for a, _ in seen] == sorted(a for a, _ in seen)
-    reg_o, w_o, st_o = _oracle_driver(oracle, video, ref, opt)
+    reg_o, w_o, st_o, _ = oracle_driver(oracle, video, ref, opt)
     epe = np.linalg.norm(w.astype(np.float64) - w_o, axis=-1)
     assert epe.mean() < 1e-4, (epe.mean(), epe.max())
     assert np.abs(reg - reg_o).max() < 0.5  # intensities ~100..1100: 5e-4 relative
