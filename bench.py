@@ -148,21 +148,53 @@ def cpu_baseline(workload, sample_edge):
                       f"{cores} volumes on {cores} cores (one process per volume) {t_all:.1f} s wall, "
                       f"{min(per):.1f}-{max(per):.1f} s each; rates scaled by voxel count to {Z}x{Y}x{X}",
             "value_1core": scale / t1, "sample_volumes_per_sec_1core": 1.0 / t1,
+            "fullsize_1core_measured": "one whole 256^3 volume (flow solve only) measured 206 s on one core of a GPU host "
+                                       "(round 1) and 414-460 s in the 8-core build container (tests/golden/fullsize_cfg2*.npz "
+                                       "metadata): the voxel-count scaling of the sample flatters the CPU by ~15 %",
             "sample_volumes_per_sec_all_cores": rate_all, "host_cpus": os.cpu_count()}
 
 
 SOLVER_NAMES = ("fp32 storage, fp32 update arithmetic", "fp32 storage, fp64 update arithmetic",
-                "fp64 storage and arithmetic")
-# mean flow end-point error against the CPU path at full size, measured by tests/test_gpu_fullsize_parity.py against
-# tests/golden/fullsize_*.npz (a property of the solver mode, not re-measured by a bench run)
-PARITY = {("cfg2", 1): 5.7e-5, ("cfg3", 1): 1.5e-4, ("cfg3", 2): 1.2e-5}
+                "fp64 storage and arithmetic", "packed 42-bit storage (three values per 16 B), fp64 update arithmetic")
+STORAGE_BYTES = (4.0, 4.0, 8.0, 16.0 / 3.0)  # per stored solver value
 
 
-def resolved_mode(solver_fp64, nvox, channels=1):
+def parity_record(workload, mode, recipe_inputs):
+    """Mean flow end-point error against the CPU path at full size as MEASURED by tests/test_gpu_fullsize_parity.py
+    (which appends to gpurun_out/parity_fullsize.json; the committed copy is profiles/parity_fullsize.json).  A property
+    of (inputs, solver mode), not re-measured by a bench run: the CPU side of one 256^3 volume takes minutes.
+    -> (value or None, where it comes from)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "parity_fullsize.json")) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        return None, "profiles/parity_fullsize.json missing"
+    for case in ((workload + "_recipe", workload) if recipe_inputs else (workload, workload + "_recipe")):
+        e = rec.get(f"{case}/mode{mode}")
+        if e:
+            same = case.endswith("_recipe") == bool(recipe_inputs)
+            return e["lattice_mean_epe"], (f"profiles/parity_fullsize.json[{case}/mode{mode}]: lattice mean EPE vs the CPU oracle, "
+                                           + ("same input recipe as this run" if same else "NOT this run's input recipe"))
+    return None, f"no full-size measurement recorded for {workload} in solver mode {mode}"
+
+
+def sweep_source_hash():
+    """identifies the sweep kernel the PMC traffic record belongs to (sources, not the binary: rebuilding unrelated
+    kernels must not invalidate it)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("k_sor.hip", "k_sor_core.h", "fr3d_internal.h"):
+        with open(os.path.join(ROOT, "flowreg3d_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def resolved_mode(solver_fp64, nvox, channels=1, a_smooth=1.0):
     """FR3D_SOLVER_AUTO as the engine resolves it (flowreg3d_amd/csrc/engine.hip: solver_mode)."""
-    if solver_fp64 >= 0:
-        return solver_fp64
-    return 2 if (channels >= 2 or nvox > (1 << 25)) else 1
+    m = solver_fp64
+    if m < 0:
+        m = 2 if channels >= 2 else (3 if nvox > (1 << 25) else 1)
+    return 2 if (m == 3 and a_smooth != 1.0) else m
 
 
 def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, world, dist, dev_index, fast_inputs,
@@ -175,7 +207,7 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
     T = K + W
     params = _lib.make_params(n_channels=1, solver_fp64=None if solver_fp64 < 0 else solver_fp64,
                               **solver_kwargs(levels, a_smooth))
-    mode = resolved_mode(solver_fp64, nv)
+    mode = resolved_mode(solver_fp64, nv, 1, a_smooth)
 
     def reference_volume():
         # texture(): blurred noise + blobs; fast_pair's O(N) stand-in where the 512^3 blur would
@@ -185,13 +217,18 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
     # ---- fixed reference: generated on rank 0, broadcast over RCCL/xGMI -----------------------
     ref_dev = DevArray(lib, (Z, Y, X, 1))
     ref_t = None
+    bcast_ms = None
     if world > 1:
         import torch
         ref_t = torch.empty((Z, Y, X), dtype=torch.float32, device=f"cuda:{dev_index}")
         if rank == 0:
             ref_t.copy_(torch.from_numpy(reference_volume()))
-        dist.broadcast(ref_t, src=0)  # the path's only collective
         torch.cuda.synchronize()
+        dist.barrier()
+        t_b = time.perf_counter()
+        dist.broadcast(ref_t, src=0)  # the path's only collective
+        torch.cuda.synchronize()      # the engine reads the buffer on its own stream: complete before any engine call
+        bcast_ms = 1e3 * (time.perf_counter() - t_b)
         fixed_ptr = ref_t.data_ptr()
     else:
         ref_dev.upload(reference_volume())
@@ -251,34 +288,56 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
     elapsed = time.perf_counter() - t0
     stats = _lib.prof_get()
     lib.fr3d_prof_enable(0)
+    per_rank = None
     if world > 1:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev_index}")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)  # timing only: every rank's own K-step time (the step time is their maximum)
+        per_rank = [float(x.item()) for x in every]
+        elapsed = max(per_rank)
+    par, par_src = parity_record(workload, mode, not fast_inputs)
     res = {"elapsed": elapsed, "stats": stats, "batch_vols": batch_vols, "desc": desc, "mode": mode,
-           "parity_mean_epe_vs_cpu": PARITY.get((workload, mode))}
+           "parity_mean_epe_vs_cpu": par, "parity_source": par_src,
+           "per_rank_volumes_per_sec": None if per_rank is None else [round(K / t, 3) for t in per_rank],
+           "broadcast": None if bcast_ms is None else {"bytes": nv * 4, "ms": round(bcast_ms, 3),
+                                                        "what": "fixed reference volume, rank 0 -> all (RCCL over xGMI)"}}
     if rank == 0:
         sor = stats["sor"]
         achieved = sor["algo_bytes"] / (sor["ms"] * 1e-3) / 1e9 if sor["ms"] > 0 else 0.0
         # HBM traffic of the SOR kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
         # correction + WRITE_SIZE), stored per voxel update in profiles/pmc_traffic.json by
         # tools/make_pmc_traffic.py -- a constant of the committed kernel, NOT measured by this run
-        traffic, traffic_source = None, None
+        traffic, traffic_source = None, "no PMC record for this workload / solver mode"
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 pj = json.load(fh)
-            pmc = pj.get(workload)
-            if pmc and mode < 2:
+            pmc = pj.get(f"{workload}/mode{mode}") if a_smooth == 1.0 else None
+            if pmc and pj.get("_sweep_source_hash") != sweep_source_hash():
+                traffic_source = ("profiles/pmc_traffic.json was taken on other sweep-kernel sources "
+                                  f"({pj.get('_sweep_source_hash')} != {sweep_source_hash()}): not quoted")
+            elif pmc:
                 traffic = pmc["bytes_per_update"] * sor["units"] / max(sor["launches"], 1)
-                traffic_source = f"profiles/pmc_traffic.json ({pj.get('_taken_at', 'unknown round')}): " \
-                                 f"{pmc['bytes_per_update']:.1f} B per voxel update x this run's updates per launch"
+                traffic_source = f"profiles/pmc_traffic.json ({pj.get('_taken_at', 'unknown round')}; same sweep-kernel " \
+                                 f"sources as this run): {pmc['bytes_per_update']:.1f} B per voxel update x this run's " \
+                                 "updates per launch -- separate rocprofv3 --pmc passes, not measured by this run"
         except (OSError, ValueError, KeyError):
             traffic = None
-        res["roofline"] = {"bound": "hbm", "kernel": "k_sor_step (SOR hyperplane sweep)",
-                           "algo_bytes_per_update": sor["algo_bytes"] / max(sor["units"], 1),
+        channels = 1
+        basis = sor["algo_bytes"] / max(sor["units"], 1)
+        vals = 10 * channels + (9 if a_smooth == 1.0 else 17)
+        # the same time priced on SURVEY 8d's fp32 figure (4 B per value: 76 B per update for C = 1, a_smooth = 1), so that
+        # legs with different storage formats stay comparable
+        frac_fp32_basis = (4.0 * vals * sor["units"] / (sor["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if sor["ms"] > 0 else 0.0
+        res["roofline"] = {"bound": "hbm",
+                           "kernel": "k_sor_step (SOR hyperplane sweep)" if a_smooth == 1.0 else
+                                     "k_smooth_step + k_smooth_psi (psi_smooth SOR sweep, a_smooth != 1)",
+                           "algo_bytes_per_update": basis,
+                           "basis": f"{vals} values per voxel update ({'9 J + w psi + 3 L + 3 d read, 3 d written' if a_smooth == 1.0 else '9 J + w psi + 3 u + 3 d + psi_s read, 3 d written; psi_s: 3 u + 3 d read, 1 written'}) "
+                                    f"x {STORAGE_BYTES[mode]:.3g} B per value in this mode's storage format",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                           "frac": achieved / HBM_PEAK_GBS, "frac_on_fp32_basis": frac_fp32_basis,
+                           "traffic": traffic, "traffic_source": traffic_source,
                            "algo_bytes_per_launch": sor["algo_bytes"] / max(sor["launches"], 1),
                            "avg_launch_us": 1e3 * sor["ms"] / max(sor["launches"], 1),
                            "launches": sor["launches"]}
@@ -367,8 +426,8 @@ def main():
         else:
             dist.init_process_group(backend)
         world = dist.get_world_size()
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if world > 1 and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} does not match the process group's world size {world}")
 
     from flowreg3d_amd import _lib
     lib = _lib.init(dev_index)
@@ -398,17 +457,19 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if m["mode"] < 2 else "f64",
+            "dtype": "f32" if m["mode"] == 0 else "f64",  # update arithmetic; storage format in config.solver
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {m['desc']}; iterations=100, update_lag=5, eta=0.8, "
                                    f"alpha=0.25, a_data=0.45, a_smooth={args.a_smooth:g}; lexicographic-exact SOR",
                        "solver": SOLVER_NAMES[m["mode"]] + (" (library's automatic choice)" if args.solver_fp64 < 0 else ""),
-                       "parity_mean_epe_vs_cpu_path": m["parity_mean_epe_vs_cpu"],
+                       "parity_mean_epe_vs_cpu_path": m["parity_mean_epe_vs_cpu"], "parity_source": m["parity_source"],
+                       "per_rank_volumes_per_sec": m["per_rank_volumes_per_sec"], "broadcast": m["broadcast"],
                        "volumes_per_gpu_per_step": 1, "lockstep_batch": m["batch_vols"],
                        "untimed_conditioning_s": args.condition if W > 0 else 0.0,
                        "sharding": f"volume-per-GPU x{world}",
                        "world_size": world, "dist_backend": backend if world > 1 else "none (single process)",
-                       "collectives": "one broadcast of the fixed reference (+ the timing all-reduce)" if world > 1 else "none",
+                       "collectives": "one broadcast of the fixed reference (+ barriers and one all_gather of the per-rank "
+                                      "step times, timing only)" if world > 1 else "none",
                        "device": lib.fr3d_device_info().decode()},
             "roofline": m["roofline"],
             "kernel_ms_per_step": m["kernel_ms_per_step"],
@@ -417,20 +478,21 @@ def main():
         if world == 1 and not args.no_extras and args.workload == "cfg2":
             # (1) the host-array entry (PCIe both ways) -- reported beside `value`, never as `value`
             out["host_path"] = host_path("cfg2", 8, None if args.solver_fp64 < 0 else args.solver_fp64)
-            # (2) the 512^3 configuration the roofline target is stated on, in both storage modes: fp64 storage is what
-            # the library chooses there (mean EPE 1.2e-5 against the CPU path; fp32 storage measures 1.5e-4, above
-            # the 1e-4 bound) and fp32 storage is the mode the 76 B / update roofline figure is defined on.
+            # (2) the 512^3 configuration the roofline target is stated on, in three storage modes: the library's choice
+            # there (packed 42-bit storage), fp32 storage (the mode SURVEY 8d's 76 B / update figure is defined on;
+            # measured parity 1.5e-4, above the 1e-4 bound) and fp64 storage (the reference-grade mode).
             # The workspace of the 256^3 run is released first.
-            for key, md, cond in (("cfg3", -1, 8.0), ("cfg3_fp32_storage", 1, 6.0)):
+            for key, md, cond in (("cfg3", -1, 8.0), ("cfg3_fp32_storage", 1, 5.0), ("cfg3_fp64_storage", 2, 5.0)):
                 _lib.shutdown()
                 lib = _lib.init(dev_index)
                 c3 = measure(lib, _lib, "cfg3", 4, 1, 0, cond, md, 0, 1, None, dev_index, fast_inputs=True)
                 out[key] = {"workload": f"cfg3: {c3['desc']}; same solver parameters", "value": 4 / c3["elapsed"],
                             "unit": "volumes/sec", "steps": 4, "warmup": 1, "ms_per_step": 1e3 * c3["elapsed"] / 4,
                             "lockstep_batch": c3["batch_vols"], "untimed_conditioning_s": cond,
-                            "dtype": "f32" if c3["mode"] < 2 else "f64",
+                            "dtype": "f32" if c3["mode"] == 0 else "f64",
                             "solver": SOLVER_NAMES[c3["mode"]] + (" (library's automatic choice)" if md < 0 else " (forced)"),
-                            "parity_mean_epe_vs_cpu_path": c3["parity_mean_epe_vs_cpu"], "roofline": c3["roofline"],
+                            "parity_mean_epe_vs_cpu_path": c3["parity_mean_epe_vs_cpu"], "parity_source": c3["parity_source"],
+                            "roofline": c3["roofline"],
                             "kernel_ms_per_step": c3["kernel_ms_per_step"], "roofline_stages": c3["roofline_stages"]}
             # (3) the psi_smooth solver path (a_smooth != 1; get_displacement's own default is 0.5, no BASELINE
             # configuration uses it): cfg2 geometry, same parameters otherwise
@@ -441,7 +503,9 @@ def main():
             out["a_smooth_0.5"] = {"workload": "cfg2 geometry with a_smooth=0.5 (psi_smooth re-evaluated every iteration)",
                                    "value": 8 / sm["elapsed"], "unit": "volumes/sec", "steps": 8, "warmup": 1,
                                    "ms_per_step": 1e3 * sm["elapsed"] / 8, "lockstep_batch": sm["batch_vols"],
-                                   "solver": SOLVER_NAMES[sm["mode"]], "kernel_ms_per_step": sm["kernel_ms_per_step"]}
+                                   "solver": SOLVER_NAMES[sm["mode"]], "parity_mean_epe_vs_cpu_path": parity_record("cfg2_asmooth05", sm["mode"], False)[0],
+                                   "parity_source": parity_record("cfg2_asmooth05", sm["mode"], False)[1],
+                                   "roofline": sm["roofline"], "kernel_ms_per_step": sm["kernel_ms_per_step"]}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -644,7 +644,10 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
             } else {
                 FR3D_HIP(hipMemsetAsync(dbuf, 0, ns * 3 * nb * sizeof(S), e.st));
             }
-            sp.add((double)sizeof(S) * (10.0 * C + 9.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
+            // algorithmic traffic of the reference's a_smooth != 1 iteration (level_solver_3d.py:400-471 + :262-311): the
+            // sweep reads 9C tensor entries + C (w psi) + 3 u,v,w + 3 d + psi_smooth and writes 3 d; psi_smooth, re-evaluated
+            // every iteration, reads 3 u,v,w + 3 d and writes 1: (10C + 17) values per voxel update
+            sp.add((double)sizeof(S) * (10.0 * C + 17.0) * (double)nl * p.iterations * nb, n, (long long)nl * p.iterations * nb);
         } else {
             throw Error("internal: packed solver storage serves the a_smooth == 1 sweep only");
         }
@@ -763,8 +766,10 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C)
         // what the solver slabs may occupy: the memory that is free now plus what the engine already
         // holds (its buffers are reused), minus a margin for the per-level scratch; never more than
         // 85 % of the device.  Memory the caller holds (a resident series, torch tensors) is respected.
+        // (the host-staging windows "stg*" of fr3d_process_batch_raw stay in use during the call: not reusable)
         size_t held = 0;
-        for (const auto &kv : g_eng.bufs) held += kv.second.cap;
+        for (const auto &kv : g_eng.bufs)
+            if (kv.first.compare(0, 3, "stg") != 0) held += kv.second.cap;
         const double avail = (double)free_b + (double)held - scratch - 2.0 * 1073741824.0;
         const double budget = std::min(0.85 * (double)total_b, avail);
         while (want > 1 && per_vol * want > budget) want--;

@@ -446,18 +446,28 @@ static bool median_flat_ok(int Z, int Y, int X, int nf)
     return X >= 8 && Y >= 3 && Z >= 3 && n < (1ll << 32) && nf >= 1 && nf <= 3;
 }
 
+// A/B aid of the experiment build (-DFR3D_EXPERIMENTS): FR3D_MEDIAN = 1 one output per thread, 2 pairs without LDS,
+// 3 row tiles.  The shipped library has no switch: mode 0.
+static int median_mode()
+{
+#ifdef FR3D_EXPERIMENTS
+    static const char *env = getenv("FR3D_MEDIAN");
+    return env ? atoi(env) : 0;
+#else
+    return 0;
+#endif
+}
+
 bool median_can_accumulate(int Z, int Y, int X)
 {
-    static const char *env = getenv("FR3D_MEDIAN");
-    return (!env || atoi(env) == 0) && median_flat_ok(Z, Y, X, 3);
+    return median_mode() == 0 && median_flat_ok(Z, Y, X, 3);
 }
 
 // nf fields of one volume (field f at in + f*fstride) in one launch; out[f] = median, or out[f] += median.
 void launch_median5_fields(hipStream_t st, const float *in, long long fstride, int nf, int Z, int Y, int X,
                            float *const *out, bool accumulate)
 {
-    static const char *env = getenv("FR3D_MEDIAN");  // A/B aid: 1 one output per thread, 2 pairs without LDS, 3 row tiles
-    const int mode = env ? atoi(env) : 0;
+    const int mode = median_mode();
     if (mode == 0 && median_flat_ok(Z, Y, X, nf)) {
         MedianDst d;
         for (int f = 0; f < 3; f++) d.p[f] = f < nf ? out[f] : nullptr;
@@ -474,8 +484,7 @@ void launch_median5_fields(hipStream_t st, const float *in, long long fstride, i
 
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out)
 {
-    static const char *env = getenv("FR3D_MEDIAN");  // A/B aid: 1 = one output per thread, 2 = pairs without LDS
-    const int mode = env ? atoi(env) : 0;
+    const int mode = median_mode();
     if (mode == 0 && median_flat_ok(Z, Y, X, 1)) {
         float *o[1] = {out};
         launch_median5_fields(st, in, 0, 1, Z, Y, X, o, false);

@@ -231,8 +231,11 @@ void launch_motion_tensor_rec(hipStream_t st, const float *f1, const float *f2, 
     constexpr int TY = sizeof(typename Sto<TA>::val) == 8 ? 16 : 32;  // 12 x TY x 34 values of LDS
     FR3D_CHECK(sk.Z <= 65535, "motion tensor: z axis longer than 65535");
     Img a{f1, sk.Z, sk.Y, sk.X}, b{f2, sk.Z, sk.Y, sk.X};
-    static const char *env = getenv("FR3D_TENSOR_DBG");
-    const int dbg = env ? atoi(env) : 0;
+    int dbg = 0;
+#ifdef FR3D_EXPERIMENTS
+    static const char *env = getenv("FR3D_TENSOR_DBG");  // disable the arithmetic (1) / the stores (2), 16-row tiles (4)
+    dbg = env ? atoi(env) : 0;
+#endif
     if (dbg & 4) {
         dim3 grid(cdiv(sk.X, TPX) * cdiv(sk.Y, 16), sk.Z);
         hipLaunchKernelGGL((k_motion_tensor_rec<TA, 16>), grid, dim3(256), 0, st, a, b, tensor_scale(hz, hy, hx), dst, sk, dbg);

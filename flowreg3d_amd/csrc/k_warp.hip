@@ -525,8 +525,10 @@ k_prefilter_x_compact(const double *__restrict__ src, long long nrows, int N, do
 
 bool prefilter_compact_ok(int Z, int Y, int X)
 {
-    static const char *env = getenv("FR3D_PREFILTER");  // A/B aid: "padded" forces the stored-pad form
+#ifdef FR3D_EXPERIMENTS
+    static const char *env = getenv("FR3D_PREFILTER");  // A/B aid (experiment build): "padded" forces the stored-pad form
     if (env && env[0] == 'p') return false;
+#endif
     return Z >= 41 && Y >= 41 && X >= 41;
 }
 

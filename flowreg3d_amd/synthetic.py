@@ -137,9 +137,10 @@ SOLVER_DEFAULTS = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=100, m
                        a_smooth=1.0, a_data=0.45)
 
 
-def fullsize_case(name):
+def fullsize_case(name, warp=None):
     """Deterministic full-size inputs of BASELINE configs 2, 3 and 5 (the cases whose CPU-path flows
-    are sampled in tests/golden/fullsize_*.npz): -> fixed, moving, flow_gt, get_displacement kwargs."""
+    are sampled in tests/golden/fullsize_*.npz): -> fixed, moving, flow_gt, get_displacement kwargs.
+    `warp`: imregister_wrapper of the side that generates the inputs (recipe cases only)."""
     if name == "cfg2":
         fixed, moving, gt = fast_pair((256, 256, 256))
         return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=4)
@@ -152,10 +153,18 @@ def fullsize_case(name):
         fixed, moving, gt = fast_pair((512, 512, 512))
         return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=5)
     if name in ("cfg2_recipe", "cfg3_recipe"):
-        # SURVEY section 8d's input recipe, the one bench.py times: texture() (blurred PCG64 noise + 8 blobs) and
-        # translation (1.7,-1.1,0.6) + 1.5 degree rotation about z, moving = backward cubic warp of fixed
+        # SURVEY section 8d's input recipe exactly as bench.py generates it: texture() (blurred PCG64 noise + 8 blobs),
+        # translation (1.7,-1.1,0.6) + 1.5 degree rotation about z, moving = the path's own cubic compensation warp of
+        # fixed by -flow with fixed as the out-of-bounds fill (imregister_wrapper, core/optical_flow_3d.py:22-74).
+        # `warp(f2, u, v, w, f1)` is that function: the CPU oracle's in the build container, the engine's on the GPU box
+        # (they agree to the last float32 bit on all but ~1 % of the voxels, which is why the fixture checks the moving
+        # volume on a sample instead of by checksum).
+        if warp is None:
+            raise ValueError("recipe cases need the imregister_wrapper to generate the moving volume with")
         n = 256 if name == "cfg2_recipe" else 512
-        fixed, moving, gt = make_pair((n, n, n), seed=1234)
+        fixed = texture((n, n, n), seed=1234)
+        gt = flow_gt((n, n, n))
+        moving = np.asarray(warp(fixed, -gt[..., 0], -gt[..., 1], -gt[..., 2], fixed), dtype=np.float32).reshape(fixed.shape)
         return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=4 if n == 256 else 5)
     if name == "cfg5_levels8":
         # the survey's own config-5 schedule (levels=8, min_level=0 -> 9 solves); the pyramid does

@@ -92,7 +92,8 @@ def test_warp_pad_free_prefilter_vs_oracle(hip, oracle, shape, dtype):
 
 
 def test_pad_free_prefilter_is_bit_identical_to_the_padded_form(hip):
-    """Same warp with FR3D_PREFILTER=padded (SciPy's layout: 12 stored pad voxels per side) in a child process."""
+    """Same warp with FR3D_PREFILTER=padded (SciPy's layout: 12 stored pad voxels per side; the switch exists in the
+    experiment build of the library only) in a child process, against the shipped library."""
     import os, subprocess, sys
     code = ("import numpy as np, hashlib, flowreg3d_amd as fr\n"
             "rng = np.random.default_rng(4)\n"
@@ -113,6 +114,8 @@ def test_pad_free_prefilter_is_bit_identical_to_the_padded_form(hip):
     out = {}
     for mode in ("compact", "padded"):
         env = dict(os.environ, FR3D_PREFILTER=mode, PYTHONPATH=root)
+        if mode == "padded":
+            env["FR3D_LIB"] = os.path.join(root, "flowreg3d_amd", "lib", "libflowreg3d_hip_exp.so")
         r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out[mode] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
@@ -234,8 +237,8 @@ def test_median_bit_exact_vs_oracle(hip, oracle, shape):
 
 def test_fused_median_update_is_bit_identical_to_separate_launches(hip):
     """The engine's default tail of a level (one launch: medians of du, dv, dw added to the flow) against the
-    separate per-field median + accumulate launches (FR3D_MEDIAN=3, read at the library's first use, hence the
-    child process): the whole get_displacement result must agree bit for bit."""
+    separate per-field median + accumulate launches (FR3D_MEDIAN=3, a switch of the experiment build of the library,
+    read at its first use, hence the child process): the whole get_displacement result must agree bit for bit."""
     import os, subprocess, sys, hashlib
     code = ("import numpy as np, hashlib, flowreg3d_amd as fr\n"
             "from flowreg3d_amd import synthetic\n"
@@ -246,6 +249,8 @@ def test_fused_median_update_is_bit_identical_to_separate_launches(hip):
     out = {}
     for mode in ("0", "3"):
         env = dict(os.environ, FR3D_MEDIAN=mode, PYTHONPATH=root)
+        if mode != "0":
+            env["FR3D_LIB"] = os.path.join(root, "flowreg3d_amd", "lib", "libflowreg3d_hip_exp.so")
         r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out[mode] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]

@@ -51,7 +51,7 @@ def main():
     args = ap.parse_args()
     from oracle import oracle
 
-    fixed, moving, gt, kw = fullsize_case(args.case)
+    fixed, moving, gt, kw = fullsize_case(args.case, warp=oracle.imregister_wrapper)
     digest = input_digest(fixed, moving)
     print(f"{args.case}: inputs {fixed.shape} sha256 {digest[:16]}..., running the oracle", flush=True)
     t0 = time.time()
@@ -61,7 +61,8 @@ def main():
     crop = 8
     meta = {"case": args.case, "shape_zyx": list(fixed.shape[:3]), "channels": 1 if fixed.ndim == 3 else fixed.shape[3],
             "params": {k: (np.asarray(v).tolist() if hasattr(v, "__len__") else v) for k, v in kw.items()},
-            "inputs_sha256": digest, "stride": args.stride, "block": args.block, "block_origin_zyx": list(org),
+            "inputs_sha256": digest, "fixed_sha256": hashlib.sha256(np.ascontiguousarray(fixed).tobytes()).hexdigest(),
+            "stride": args.stride, "block": args.block, "block_origin_zyx": list(org),
             "oracle_seconds_1core": dt,
             "epe_oracle_vs_gt_mean_interior8": epe(flow, gt, crop)[0],
             "epe_oracle_vs_gt_max_interior8": epe(flow, gt, crop)[1],
@@ -70,6 +71,7 @@ def main():
     np.savez_compressed(os.path.join(args.out, f"fullsize_{args.case}.npz"),
                         lattice=lat.astype(np.float32), block=blk.astype(np.float64),
                         gt_lattice=np.ascontiguousarray(gt[::args.stride, ::args.stride, ::args.stride]).astype(np.float32),
+                        moving_lattice=np.ascontiguousarray(moving[::args.stride, ::args.stride, ::args.stride]),
                         meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
     print(json.dumps(meta), flush=True)
 
