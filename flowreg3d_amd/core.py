@@ -184,6 +184,39 @@ def imresize_fused_gauss_cubic3D(img, size, sigma_coeff=0.6, per_axis=False):
     return out.astype(img.dtype, copy=False)
 
 
+def get_displacement_verify(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=20, min_level=0,
+                            levels=50, eta=0.8, a_smooth=1.0, a_data=0.45, uvw=None, weight=None):
+    """Verification mode of ``get_displacement`` (fr3d_get_displacement_verify, a_smooth == 1): the reference's own
+    arithmetic (core/level_solver_3d.py:356-377,472-540: fp64, expanded quadratic form, per-channel order, true
+    divisions) on the engine's data path, the level flow kept in float64 like the reference's.  Bit-identical to the
+    CPU restatement of the reference built with the same portable pow (its ``ppow`` build); ~5x slower than the fp64-storage mode.
+    -> (Z,Y,X,3) float64."""
+    fixed = np.asarray(fixed)
+    moving = np.asarray(moving)
+    if fixed.ndim == 3:
+        fixed = fixed[..., None]
+        moving = moving[..., None]
+    if fixed.ndim != 4 or moving.shape != fixed.shape:
+        raise ValueError("fixed and moving must have the same (Z,Y,X[,C]) shape")
+    if float(a_smooth) != 1.0:
+        raise NotImplementedError("the verification mode covers the a_smooth == 1 solver")
+    p, m, n, nc = fixed.shape
+    wt = expand_weight(weight, p, m, n, nc)
+    params = _lib.make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth, a_data, nc, 2)
+    f32, m32 = _f32c(fixed), _f32c(moving)
+    u32 = None
+    if uvw is not None:
+        u32 = _f32c(uvw)
+        if u32.shape != (p, m, n, 3):
+            raise ValueError("uvw must have shape (Z,Y,X,3)")
+    w32 = None if wt is None else _f32c(wt)
+    out = np.empty((p, m, n, 3), np.float64)
+    lib = _lib.init()
+    _lib.check(lib.fr3d_get_displacement_verify(C.byref(params), _lib.ptr(f32), _lib.ptr(m32), p, m, n, nc, _lib.ptr(u32),
+                                                _lib.ptr(w32), _lib.ptr(out)))
+    return out
+
+
 def get_motion_tensor_gc(f1, f2, hz, hy, hx, return_factors=False):
     """core/optical_flow_3d.py:92-152 -> 10 arrays (Z+2,Y+2,X+2) float64, outer ring zero, in the
     order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34.  Values are the engine's fp32 storage.

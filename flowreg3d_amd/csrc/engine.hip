@@ -696,6 +696,132 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Verification mode (k_verify.hip): get_displacement with the reference's arithmetic, fp64 end to end, on the
+// engine's data path -- compact skewed layout, hyperplane schedule, the pyramid's resampler / prefilter / gather /
+// tensor stages.  One volume, no lock-step batch, no timing spans.  flow_out: (Z,Y,X,3) fp64 on the device.
+// Mirrors core/optical_flow_3d.py:389-542 statement by statement (the level flow stays fp64 between the stages like
+// the reference's `u = u + du`, and is rounded to fp32 only where the reference's resampler does it, :116 of
+// util/resize_util_3D.py).
+// ---------------------------------------------------------------------------------------------
+static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::vector<Level> &lv, int min_level,
+                                    const RefPyramid &rp, const float *moving, int Z, int Y, int X, int C,
+                                    const float *uvw_init, double *flow_out)
+{
+    FR3D_CHECK(p.a_smooth == 1.0, "verification mode covers the a_smooth == 1 solver");
+    const size_t nfull = (size_t)Z * Y * X;
+    double *ud[3] = {nullptr, nullptr, nullptr}, *ud_prev[3] = {nullptr, nullptr, nullptr};
+    int pz = 0, py = 0, px = 0, flip = 0;
+    for (size_t li = 0; li < lv.size(); li++) {
+        const Level &L = lv[li];
+        const int lz = L.z, ly = L.y, lx = L.x;
+        const size_t nl = (size_t)lz * ly * lx;
+        const double hz = (double)Z / lz, hy = (double)Y / ly, hx = (double)X / lx;
+        const float *f1l = rp.f1[li];
+        const Skew sk = e.compact_skew(lz, ly, lx);
+        const size_t ns = (size_t)sk.total;
+        const float *f2l = moving;
+        if (!(C == 1 && lz == Z && ly == Y && lx == X)) {
+            float *buf = e.f32("f2l", nl * C);
+            for (int c = 0; c < C; c++) resize3d(e, moving, C, c, Z, Y, X, lz, ly, lx, buf + (size_t)c * nl);
+            f2l = buf;
+        }
+        // level flow: fp32 out of the resampler (:417-434), fp64 from here on
+        const std::string sfx = flip ? "_a" : "_b";
+        flip ^= 1;
+        float *uf = e.f32("vf_uf", nl * 3);
+        for (int d = 0; d < 3; d++) {
+            ud_prev[d] = ud[d];
+            ud[d] = e.f64(std::string("vf_u") + char('0' + d) + sfx, nl);
+        }
+        const float *warped = f2l;
+        if (li == 0) {
+            for (int d = 0; d < 3; d++) {
+                if (uvw_init) resize3d(e, uvw_init, 3, d, Z, Y, X, lz, ly, lx, uf + (size_t)d * nl);
+                else launch_fill(e.st, uf + (size_t)d * nl, 0.0f, (long long)nl);
+            }
+        } else {
+            const size_t nprev = (size_t)pz * py * px;
+            float *prevf = e.f32("vf_prev", nprev);
+            for (int d = 0; d < 3; d++) {
+                launch_cast<double, float>(e.st, ud_prev[d], (long long)nprev, prevf);
+                resize3d(e, prevf, 1, 0, pz, py, px, lz, ly, lx, uf + (size_t)d * nl);
+            }
+            float *wbuf = e.f32("warped", nl * C);
+            for (int c = 0; c < C; c++)
+                warp_cubic_chan<float, float>(e, f2l + (size_t)c * nl, 1, 0, uf, uf + nl, uf + 2 * nl, 1, hx, hy, hz,
+                                              f1l + (size_t)c * nl, lz, ly, lx, wbuf + (size_t)c * nl, 1, 0);
+            warped = wbuf;
+        }
+        for (int d = 0; d < 3; d++) launch_cast<float, double>(e.st, uf + (size_t)d * nl, (long long)nl, ud[d]);
+
+        // operands of the sweep as records on the compact skewed rows
+        double *Jnat = e.f64("vf_Jnat", nl * 10);
+        double *Jrec = e.f64("vf_Jrec", ns * 10 * C);
+        float *wrec = e.f32("vf_wrec", ns * C);
+        double *psi = e.f64("vf_psi", ns * C);
+        double *Urec = e.f64("vf_Urec", ns * 3);
+        double *Drec = e.f64("vf_Drec", ns * 3);
+        VerifyArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.sk = sk;
+        a.C = C;
+        a.update_lag = p.update_lag;
+        for (int c = 0; c < C; c++) {
+            double *Jo[10];
+            for (int q = 0; q < 10; q++) Jo[q] = Jnat + (size_t)q * nl;
+            launch_motion_tensor<double, double>(e.st, f1l + (size_t)c * nl, warped + (size_t)c * nl, lz, ly, lx, hz, hy, hx, Jo,
+                                                 (double *)nullptr, 0, nullptr);
+            launch_skew_pack<double, double>(e.st, Jnat, (long long)nl, Jrec + (size_t)c * 10 * ns, 10, sk);
+            launch_skew_pack<float, float>(e.st, rp.wl[li] + (size_t)c * nl, 0, wrec + (size_t)c * ns, 1, sk);
+            a.J[c] = Jrec + (size_t)c * 10 * ns;
+            a.w[c] = wrec + (size_t)c * ns;
+            a.psi[c] = psi + (size_t)c * ns;
+            a.a_data[c] = p.a_data[c];
+        }
+        launch_skew_pack<float, double>(e.st, uf, (long long)nl, Urec, 3, sk);
+        FR3D_HIP(hipMemsetAsync(Drec, 0, ns * 3 * sizeof(double), e.st));
+        a.U = Urec;
+        a.D = Drec;
+        // alpha schedule (:485-490) and alpha / h^2 (level_solver_3d.py:473-475)
+        const double sc = (L.idx == min_level) ? 1.0 : std::pow(p.eta, -0.5 * (double)L.idx);
+        a.ax = (sc * p.alpha[0]) / (hx * hx);
+        a.ay = (sc * p.alpha[1]) / (hy * hy);
+        a.az = (sc * p.alpha[2]) / (hz * hz);
+        launch_sor_verify(e.st, a, e.chain_sched(sk, p.iterations));
+        // :517-529 in fp64: increments back to the natural order, 5^3 median, u = u + du
+        double *dn = e.f64("vf_dnat", nl * 3);
+        launch_unskew_unpack<double, double>(e.st, Drec, dn, (long long)nl, 3, sk);
+        const bool med = std::min(lz, std::min(ly, lx)) > 5;
+        double *dm = med ? e.f64("vf_dmed", nl) : nullptr;
+        for (int d = 0; d < 3; d++) {
+            const double *inc = dn + (size_t)d * nl;
+            if (med) {
+                launch_median5_f64(e.st, inc, lz, ly, lx, dm);
+                inc = dm;
+            }
+            launch_axpy_f64(e.st, ud[d], inc, (long long)nl);
+        }
+        pz = lz; py = ly; px = lx;
+    }
+    // :530-541
+    const size_t nl = (size_t)pz * py * px;
+    if (min_level > 0) {
+        float *lo = e.f32("vf_prev", nl);
+        float *hi = e.f32("vf_uf", nfull);
+        double *full = e.f64("vf_dnat", nfull * 3);
+        for (int d = 0; d < 3; d++) {
+            launch_cast<double, float>(e.st, ud[d], (long long)nl, lo);
+            resize3d(e, lo, 1, 0, pz, py, px, Z, Y, X, hi);
+            launch_cast<float, double>(e.st, hi, (long long)nfull, full + (size_t)d * nfull);
+        }
+        launch_pack3_f64(e.st, full, full + nfull, full + 2 * nfull, (long long)nfull, flow_out);
+    } else {
+        FR3D_CHECK(nl == nfull, "internal: finest level is not full resolution");
+        launch_pack3_f64(e.st, ud[0], ud[1], ud[2], (long long)nfull, flow_out);
+    }
+}
+
 // FR3D_SOLVER_AUTO picks the cheapest mode that keeps the flow within 1e-4 voxels (mean end-point error) of the
 // reference CPU path, as measured against full CPU runs (tests/test_gpu_fullsize_parity.py):
 //  * one channel, up to 2^25 voxels (256^3 = 2^24: 5.7e-5): fp32 storage with fp64 update arithmetic -- the
@@ -1232,6 +1358,39 @@ int fr3d_get_displacement(const fr3d_params *p, const float *fixed, const float 
     float *dout = (float *)s.alloc(nv * 3 * 4);
     get_displacement_dev(p, df, dm, Z, Y, X, C, du, dw, dout);
     FR3D_HIP(hipMemcpy(flow_out, dout, nv * 3 * 4, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_get_displacement_verify(const fr3d_params *p, const float *fixed, const float *moving, int Z, int Y, int X,
+                                 int C, const float *uvw_init, const float *weight, double *flow_out)
+{
+    FR3D_TRY
+    ensure_init();
+    check_params(p, Z, Y, X, C);
+    FR3D_CHECK(fixed && moving && flow_out, "NULL volume pointer");
+    Engine &e = g_eng;
+    const size_t nv = (size_t)Z * Y * X;
+    Staged s;
+    const float *df = (const float *)s.up(fixed, nv * C * 4);
+    const float *dm = (const float *)s.up(moving, nv * C * 4);
+    const float *du = (const float *)s.up(uvw_init, nv * 3 * 4);
+    const float *dw = (const float *)s.up(weight, nv * C * 4);
+    double *dout = (double *)s.alloc(nv * 3 * 8);
+    int min_level = p->min_level;
+    std::vector<Level> lv = make_schedule(Z, Y, X, p->eta, p->levels, min_level);
+    RefPyramid rp;
+    build_ref_pyramid(e, lv, df, dw, Z, Y, X, C, rp, "gd_");
+    const bool prof = e.prof;
+    e.prof = false;  // not a timed path
+    try {
+        get_displacement_verify(e, *p, lv, min_level, rp, dm, Z, Y, X, C, du, dout);
+    } catch (...) {
+        e.prof = prof;
+        throw;
+    }
+    e.prof = prof;
+    FR3D_HIP(hipStreamSynchronize(e.st));
+    FR3D_HIP(hipMemcpy(flow_out, dout, nv * 3 * 8, hipMemcpyDeviceToHost));
     FR3D_CATCH
 }
 

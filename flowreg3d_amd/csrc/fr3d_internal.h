@@ -199,6 +199,26 @@ struct SorArgsT {
 };
 using SorArgs = SorArgsT<float>;
 
+// ---- verification mode (k_verify.hip): the reference's arithmetic on the compact skewed layout, fp64 ----
+struct VerifyArgs {
+    Skew sk;
+    const double *J[FR3D_MAX_CHANNELS];  // records of 10 per voxel: J11,J22,J33,J44,J12,J13,J23,J14,J24,J34
+    const float *w[FR3D_MAX_CHANNELS];   // channel weight per voxel (resampled fp32 values)
+    double *psi[FR3D_MAX_CHANNELS];      // psi_data per voxel, written on update iterations
+    const double *U;                     // u,v,w of the level, records of 3
+    double *D;                           // du,dv,dw, records of 3, updated in place
+    double ax, ay, az;                   // alpha / h^2
+    double a_data[FR3D_MAX_CHANNELS];
+    int C, update_lag;
+};
+struct SorChainSched;
+long long launch_sor_verify(hipStream_t st, const VerifyArgs &a, const SorChainSched &sc);
+void launch_median5_f64(hipStream_t st, const double *in, int Z, int Y, int X, double *out);
+template <typename TS, typename TD>
+void launch_cast(hipStream_t st, const TS *src, long long n, TD *dst);
+void launch_axpy_f64(hipStream_t st, double *y, const double *x, long long n);
+void launch_pack3_f64(hipStream_t st, const double *a, const double *b, const double *c, long long n, double *out);
+
 // ---- a_smooth != 1 solver path (k_sor_smooth.hip) ------------------------------------------------
 #define SM_LAG 4  // hyperplanes between consecutive in-flight iterations on this path
 template <typename S>
@@ -268,9 +288,9 @@ void launch_warp_linear(hipStream_t st, const TV *vol, int vcs, int vco, const T
 // K3 motion tensor: f1,f2 planar (Z,Y,X) fp32.  Jout[a] for a = J11,J22,J33,J44,J12,J13,J23,
 // J14,J24,J34; A (nullable): 12 factor arrays a_stride apart; written skewed (sk != nullptr) or
 // natural.
-template <typename TA>
+template <typename TA, typename TJ = float>
 void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int Z, int Y, int X,
-                          double hz, double hy, double hx, float *const Jout[10], TA *A,
+                          double hz, double hy, double hx, TJ *const Jout[10], TA *A,
                           long long a_stride, const Skew *sk);
 
 // K3 straight into the solver's record layout: dst = 12 factor values per voxel in the (compact or pitched)

@@ -573,7 +573,11 @@ void launch_skew_pack(hipStream_t st, const TS *src, long long src_stride, TD *d
     if (nrec == 1) launch_pack_t<TS, TD, 1, true>(st, src, src_stride, dst, sk);
     else if (nrec == 3) launch_pack_t<TS, TD, 3, true>(st, src, src_stride, dst, sk);
     else if (nrec == 12) launch_pack_t<TS, TD, 12, true>(st, src, src_stride, dst, sk);
-    else throw Error("internal: records of 1, 3 or 12 values");
+    else if (nrec == 10) {
+        if constexpr (std::is_same<TS, double>::value && std::is_same<TD, double>::value)  // verification mode: tensor entries
+            launch_pack_t<TS, TD, 10, true>(st, src, src_stride, dst, sk);
+        else throw Error("internal: records of 10 values are fp64");
+    } else throw Error("internal: records of 1, 3, 10 or 12 values");
 }
 template <typename TS, typename TD>
 void launch_unskew_unpack(hipStream_t st, const TS *src, TD *dst, long long dst_stride, int nrec, const Skew &sk)
@@ -587,6 +591,7 @@ template void launch_skew_pack<float, double>(hipStream_t, const float *, long l
 template void launch_unskew_unpack<float, float>(hipStream_t, const float *, float *, long long, int, const Skew &);
 template void launch_unskew_unpack<double, float>(hipStream_t, const double *, float *, long long, int, const Skew &);
 template void launch_unskew_unpack<pk42, float>(hipStream_t, const pk42 *, float *, long long, int, const Skew &);
+template void launch_unskew_unpack<double, double>(hipStream_t, const double *, double *, long long, int, const Skew &);
 
 // L = ax*(u_ip + u_im - 2u) + ay*(...) + az*(...) with edge-padded u (add_boundary,
 // core/optical_flow_3d.py:88), evaluated in fp64 from the fp32-exact level flow.

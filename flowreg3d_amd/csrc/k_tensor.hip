@@ -145,11 +145,11 @@ __device__ __forceinline__ void tensor_factors12(const TensorVox &v, double (&A)
     A[8] = qz * v.fxz; A[9] = qz * v.fyz; A[10] = qz * v.fzz; A[11] = qz * v.fzt;
 }
 
-template <typename TA>
+template <typename TA, typename TJ>
 __global__ void __launch_bounds__(256)
-k_motion_tensor(Img f1, Img f2, TensorScale hs, float *J11, float *J22,
-                float *J33, float *J44, float *J12, float *J13, float *J23, float *J14, float *J24,
-                float *J34, TA *A, long long a_stride, int skewed, int Yp, long long plane)
+k_motion_tensor(Img f1, Img f2, TensorScale hs, TJ *J11, TJ *J22,
+                TJ *J33, TJ *J44, TJ *J12, TJ *J13, TJ *J23, TJ *J14, TJ *J24,
+                TJ *J34, TA *A, long long a_stride, int skewed, int Yp, long long plane)
 {
     const int Z = f1.Z, Y = f1.Y, X = f1.X;
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,16 +165,16 @@ k_motion_tensor(Img f1, Img f2, TensorScale hs, float *J11, float *J22,
 
     size_t o = skewed ? (size_t)sk_index(X, Yp, plane, z, y, x) : (size_t)t;
     if (J11) {
-    J11[o] = (float)(rx * (fxx * fxx) + ry * (fxy * fxy) + rz * (fxz * fxz));
-    J22[o] = (float)(rx * (fxy * fxy) + ry * (fyy * fyy) + rz * (fyz * fyz));
-    J33[o] = (float)(rx * (fxz * fxz) + ry * (fyz * fyz) + rz * (fzz * fzz));
-    if (J44) J44[o] = (float)(rx * (fxt * fxt) + ry * (fyt * fyt) + rz * (fzt * fzt));
-    J12[o] = (float)(rx * fxx * fxy + ry * fxy * fyy + rz * fxz * fyz);
-    J13[o] = (float)(rx * fxx * fxz + ry * fxy * fyz + rz * fxz * fzz);
-    J23[o] = (float)(rx * fxy * fxz + ry * fyy * fyz + rz * fyz * fzz);
-    J14[o] = (float)(rx * fxx * fxt + ry * fxy * fyt + rz * fxz * fzt);
-    J24[o] = (float)(rx * fxy * fxt + ry * fyy * fyt + rz * fyz * fzt);
-    J34[o] = (float)(rx * fxz * fxt + ry * fyz * fyt + rz * fzz * fzt);
+    J11[o] = (TJ)(rx * (fxx * fxx) + ry * (fxy * fxy) + rz * (fxz * fxz));
+    J22[o] = (TJ)(rx * (fxy * fxy) + ry * (fyy * fyy) + rz * (fyz * fyz));
+    J33[o] = (TJ)(rx * (fxz * fxz) + ry * (fyz * fyz) + rz * (fzz * fzz));
+    if (J44) J44[o] = (TJ)(rx * (fxt * fxt) + ry * (fyt * fyt) + rz * (fzt * fzt));
+    J12[o] = (TJ)(rx * fxx * fxy + ry * fxy * fyy + rz * fxz * fyz);
+    J13[o] = (TJ)(rx * fxx * fxz + ry * fxy * fyz + rz * fxz * fzz);
+    J23[o] = (TJ)(rx * fxy * fxz + ry * fyy * fyz + rz * fyz * fzz);
+    J14[o] = (TJ)(rx * fxx * fxt + ry * fxy * fyt + rz * fxz * fzt);
+    J24[o] = (TJ)(rx * fxy * fxt + ry * fyy * fyt + rz * fyz * fzt);
+    J34[o] = (TJ)(rx * fxz * fxt + ry * fyz * fyt + rz * fzz * fzt);
     }
     if (A) {
         double a12[12];
@@ -252,22 +252,25 @@ template void launch_motion_tensor_rec<double>(hipStream_t, const float *, const
 template void launch_motion_tensor_rec<pk42>(hipStream_t, const float *, const float *, double, double, double, pk42 *,
                                              const Skew &);
 
-template <typename TA>
+template <typename TA, typename TJ>
 void launch_motion_tensor(hipStream_t st, const float *f1, const float *f2, int Z, int Y, int X,
-                          double hz, double hy, double hx, float *const J[10], TA *A,
+                          double hz, double hy, double hx, TJ *const J[10], TA *A,
                           long long a_stride, const Skew *sk)
 {
     long long total = (long long)Z * Y * X;
     Img a{f1, Z, Y, X}, b{f2, Z, Y, X};
-    hipLaunchKernelGGL(k_motion_tensor<TA>, dim3(cdiv(total, 256)), dim3(256), 0, st, a, b, tensor_scale(hz, hy, hx),
+    hipLaunchKernelGGL((k_motion_tensor<TA, TJ>), dim3(cdiv(total, 256)), dim3(256), 0, st, a, b, tensor_scale(hz, hy, hx),
                        J[0], J[1], J[2], J[3], J[4], J[5], J[6], J[7], J[8], J[9], A, a_stride, sk ? 1 : 0,
                        sk ? sk->Yp : 0, sk ? sk->plane : 0LL);
     FR3D_LAUNCH_CHECK();
 }
 
-template void launch_motion_tensor<float>(hipStream_t, const float *, const float *, int, int, int, double, double,
-                                          double, float *const[10], float *, long long, const Skew *);
-template void launch_motion_tensor<double>(hipStream_t, const float *, const float *, int, int, int, double, double,
-                                           double, float *const[10], double *, long long, const Skew *);
+template void launch_motion_tensor<float, float>(hipStream_t, const float *, const float *, int, int, int, double, double,
+                                                 double, float *const[10], float *, long long, const Skew *);
+template void launch_motion_tensor<double, float>(hipStream_t, const float *, const float *, int, int, int, double, double,
+                                                  double, float *const[10], double *, long long, const Skew *);
+// verification mode: the fp64 tensor entries as the reference forms them (no rounding to storage)
+template void launch_motion_tensor<double, double>(hipStream_t, const float *, const float *, int, int, int, double, double,
+                                                   double, double *const[10], double *, long long, const Skew *);
 
 }  // namespace fr3d

@@ -156,7 +156,7 @@ def fullsize_case(name, warp=None):
         # SURVEY section 8d's input recipe exactly as bench.py generates it: texture() (blurred PCG64 noise + 8 blobs),
         # translation (1.7,-1.1,0.6) + 1.5 degree rotation about z, moving = the path's own cubic compensation warp of
         # fixed by -flow with fixed as the out-of-bounds fill (imregister_wrapper, core/optical_flow_3d.py:22-74).
-        # `warp(f2, u, v, w, f1)` is that function: the CPU oracle's in the build container, the engine's on the GPU box
+        # `warp(f2, u, v, w, f1)` is that function: the CPU restatement's in the build container, the engine's on the GPU box
         # (they agree to the last float32 bit on all but ~1 % of the voxels, which is why the fixture checks the moving
         # volume on a sample instead of by checksum).
         if warp is None:

@@ -89,6 +89,17 @@ int fr3d_get_displacement_dev(const fr3d_params *p, const float *fixed, const fl
                               int Z, int Y, int X, int C, const float *uvw_init,
                               const float *weight, float *flow_out);
 
+/* VERIFICATION mode of fr3d_get_displacement (host pointers, one volume, a_smooth == 1): the same pyramid on the same
+ * data path -- compact skewed solver layout, hyperplane launch schedule, resampler / prefilter / gather / tensor /
+ * median stages -- with the solver evaluated exactly as core/level_solver_3d.py:356-377,472-540 writes it (fp64, expanded
+ * quadratic form, per-channel accumulation order, true divisions, no FMA contraction) and the level flow kept in fp64
+ * like the reference's `u = u + du`.  psi goes through the portable pow of flowreg3d_amd/csrc/portable_pow.h, the one the
+ * `ppow` build of the CPU oracle uses: against that build the result is BIT-IDENTICAL, at any size
+ * (tests/test_gpu_verify_mode.py).  About 5x slower than the fp64-storage mode; not a production mode.
+ * flow_out: (Z,Y,X,3) float64. */
+int fr3d_get_displacement_verify(const fr3d_params *p, const float *fixed, const float *moving, int Z, int Y, int X,
+                                 int C, const float *uvw_init, const float *weight, double *flow_out);
+
 /* imregister_wrapper (core/optical_flow_3d.py:22-74): backward warp of `vol` by `flow`,
  * out-of-bounds voxels taken from `ref`.  order 3 = cubic B-spline with SciPy's prefilter,
  * order 1 = linear.  vol/ref (Z,Y,X,C) of vol_dtype; flow (Z,Y,X,3) of flow_dtype;

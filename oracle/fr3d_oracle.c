@@ -12,6 +12,18 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* The psi nonlinearities a (x + eps)^(a-1) (core/level_solver_3d.py:310,377) use the C library's pow -- what the
+ * reference's Python floats do -- in the default build.  The `ppow` build (-DFR3D_ORACLE_PORTABLE_POW,
+ * _build/libfr3d_oracle_ppow.so) takes a pow written in plain arithmetic instead, the same source the engine's
+ * verification mode compiles for the GPU, so that the two sides can be compared BIT FOR BIT
+ * (tests/test_gpu_verify_mode.py); it differs from the default build only through the last bits of psi. */
+#ifdef FR3D_ORACLE_PORTABLE_POW
+#include "../flowreg3d_amd/csrc/portable_pow.h"
+#define PSI_POW(x, y) fr3d_ppow((x), (y))
+#else
+#define PSI_POW(x, y) pow((x), (y))
+#endif
+
 #define IDX3(z, y, x, Y, X) (((size_t)(z) * (size_t)(Y) + (size_t)(y)) * (size_t)(X) + (size_t)(x))
 
 static void *xmalloc(size_t n)
@@ -574,7 +586,7 @@ static void nonlinearity_smoothness_3d(double *psi, const double *u, const doubl
                 double g = ux * ux + uy * uy + uz * uz + vx * vx + vy * vy + vz * vz + wx * wx +
                            wy * wy + wz * wz;
                 if (g < 0.0) g = 0.0;
-                psi[IDX3(k, j, i, m, n)] = a * pow(g + eps, a - 1.0);
+                psi[IDX3(k, j, i, m, n)] = a * PSI_POW(g + eps, a - 1.0);
             }
     free(uu); free(vv); free(ww);
 }
@@ -615,7 +627,7 @@ void fr3d_oracle_compute_flow_3d(const double *const J[10], const double *weight
                                      2.0 * J14[qc] * du[q] + 2.0 * J24[qc] * dv[q] +
                                      2.0 * J34[qc] * dw[q] + J44[qc];
                         if (val < 0.0) val = 0.0;
-                        psi[qc] = adc * pow(val + eps, adc - 1.0);
+                        psi[qc] = adc * PSI_POW(val + eps, adc - 1.0);
                     }
                 }
             }

@@ -34,6 +34,14 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def use_build(name: str = ""):
+    """Select the oracle build for this process: "" = default (C library pow), "ppow" = portable pow in the psi
+    nonlinearities (bit-comparable with the engine's verification mode), "fma" = FMA-contracted timing build."""
+    global _SO, _lib
+    _SO = os.path.join(_HERE, "_build", f"libfr3d_oracle{'_' + name if name else ''}.so")
+    _lib = None
+
+
 def lib():
     global _lib
     if _lib is None:

@@ -48,8 +48,14 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--stride", type=int, default=8)
     ap.add_argument("--block", type=int, default=32)
+    ap.add_argument("--ppow", action="store_true",
+                    help="run the `ppow` build of the oracle (portable pow in the psi nonlinearities) and keep the lattice in "
+                         "float64: the sample the engine's verification mode is compared with bit for bit -> fullsize_<case>_ppow.npz")
     args = ap.parse_args()
     from oracle import oracle
+    oracle.build()
+    if args.ppow:
+        oracle.use_build("ppow")
 
     fixed, moving, gt, kw = fullsize_case(args.case, warp=oracle.imregister_wrapper)
     digest = input_digest(fixed, moving)
@@ -67,9 +73,10 @@ def main():
             "epe_oracle_vs_gt_mean_interior8": epe(flow, gt, crop)[0],
             "epe_oracle_vs_gt_max_interior8": epe(flow, gt, crop)[1],
             "flow_mean": [float(x) for x in flow.mean(axis=(0, 1, 2))],
+            "oracle_build": "ppow (portable pow in psi)" if args.ppow else "default (C library pow)",
             "generator": "tools/gen_fullsize_golden.py; oracle = oracle/fr3d_oracle.c (pinned by tests/golden/*.npz)"}
-    np.savez_compressed(os.path.join(args.out, f"fullsize_{args.case}.npz"),
-                        lattice=lat.astype(np.float32), block=blk.astype(np.float64),
+    np.savez_compressed(os.path.join(args.out, f"fullsize_{args.case}{'_ppow' if args.ppow else ''}.npz"),
+                        lattice=lat.astype(np.float64 if args.ppow else np.float32), block=blk.astype(np.float64),
                         gt_lattice=np.ascontiguousarray(gt[::args.stride, ::args.stride, ::args.stride]).astype(np.float32),
                         moving_lattice=np.ascontiguousarray(moving[::args.stride, ::args.stride, ::args.stride]),
                         meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
