@@ -130,7 +130,8 @@ def process_series_sharded(batch: Optional[np.ndarray], batch_proc: Optional[np.
                            w_init: Optional[np.ndarray], flow_params: Optional[dict],
                            interpolation_method: str = "cubic", executor=None,
                            n_volumes: Optional[int] = None,
-                           load_volume=None, device_payload: Optional[bool] = None
+                           load_volume=None, device_payload: Optional[bool] = None,
+                           window: Optional[int] = None
                            ) -> Tuple[List[int], np.ndarray, np.ndarray]:
     """Register this rank's shard of a series.
 
@@ -138,6 +139,9 @@ def process_series_sharded(batch: Optional[np.ndarray], batch_proc: Optional[np.
     flow_params); other ranks may pass None for those and receive them by broadcast.  Each rank
     supplies its volumes either as full arrays `batch`/`batch_proc` (T,Z,Y,X,C) indexed by global t,
     or through `load_volume(t) -> (raw, proc)` with `n_volumes` (data-parallel loading).
+
+    `window`: with `load_volume`, the rank loads and registers its shard `window` volumes at a time (host memory holds
+    one window of inputs; BASELINE config 4: 64 time points, 8 per rank, windows of one lock-step batch).
 
     `device_payload` (default: True with the nccl backend and the built-in executor): the broadcast buffer
     stays in HBM and the engine reads reference, weight and w_init from it (``fr3d_process_batch_raw_dev``) --
@@ -174,17 +178,30 @@ def process_series_sharded(batch: Optional[np.ndarray], batch_proc: Optional[np.
 
     T = int(n_volumes if n_volumes is not None else batch.shape[0])
     mine = shard_indices(T, rank, world)
-    if load_volume is not None:
-        pairs = [load_volume(t) for t in mine]
-        local_raw = np.stack([p[0] for p in pairs]) if pairs else None
-        local_proc = np.stack([p[1] for p in pairs]) if pairs else None
-    else:
-        local_raw = batch[mine]
-        local_proc = batch_proc[mine]
     if executor is None:
         from .executor import HipExecutor3D
         executor = HipExecutor3D(device=local_device_index() if (dist and world > 1) else None)
         executor.setup()
+
+    def windows():
+        """this rank's volumes as (raw, proc) stacks, one window at a time"""
+        if load_volume is None:
+            if mine:
+                yield batch[mine], batch_proc[mine]
+            return
+        step = len(mine) if not window else max(1, int(window))
+        for i in range(0, len(mine), max(step, 1)):
+            pairs = [load_volume(t) for t in mine[i:i + step]]
+            yield np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+
+    def collect(run):
+        regs, flws = [], []
+        for raw, proc in windows():
+            r, f = run(raw, proc)
+            regs.append(r)
+            flws.append(f)
+        return (np.concatenate(regs), np.concatenate(flws)) if regs else (None, None)
+
     if on_device:
         # device addresses of the payload's fields inside the broadcast buffer
         ptrs, shapes, off = {}, {}, 0
@@ -198,8 +215,8 @@ def process_series_sharded(batch: Optional[np.ndarray], batch_proc: Optional[np.
         Z, Y, X, nc = shapes["reference_proc"]
         if not mine:
             return mine, np.empty((0, Z, Y, X, nc), np.float32), np.empty((0, Z, Y, X, 3), np.float32)
-        registered, flows = executor.process_batch_device_refs(local_raw, local_proc, ptrs, (Z, Y, X, nc),
-                                                               interpolation_method=interpolation_method, flow_params=fp)
+        registered, flows = collect(lambda raw, proc: executor.process_batch_device_refs(
+            raw, proc, ptrs, (Z, Y, X, nc), interpolation_method=interpolation_method, flow_params=fp))
         del flat
         return mine, registered, flows
     if payload["weight"] is not None:
@@ -209,7 +226,7 @@ def process_series_sharded(batch: Optional[np.ndarray], batch_proc: Optional[np.
     if not mine:
         Z, Y, X, nc = ref_proc.shape
         return mine, np.empty((0, Z, Y, X, nc), np.float32), np.empty((0, Z, Y, X, 3), np.float32)
-    registered, flows = executor.process_batch(local_raw, local_proc, ref_raw, ref_proc, payload["w_init"],
-                                               None, None, interpolation_method=interpolation_method,
-                                               flow_params=fp)
+    registered, flows = collect(lambda raw, proc: executor.process_batch(
+        raw, proc, ref_raw, ref_proc, payload["w_init"], None, None, interpolation_method=interpolation_method,
+        flow_params=fp))
     return mine, registered, flows

@@ -49,7 +49,7 @@ class Options:
     interpolation_method: str = "cubic"
     update_initialization_w: bool = True
     update_reference: bool = False
-    solver_fp64: Optional[int] = None  # extension: None = fp32 solver storage (fp64 update arithmetic) for one channel, fp64 storage for several
+    solver_fp64: Optional[int] = None  # extension: None = the library's choice (fr3d_params.solver_fp64: by size and channel count)
 
     @property
     def effective_min_level(self) -> int:

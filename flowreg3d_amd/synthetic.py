@@ -152,7 +152,7 @@ def fullsize_case(name, warp=None):
     if name == "cfg3":
         fixed, moving, gt = fast_pair((512, 512, 512))
         return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=5)
-    if name in ("cfg2_recipe", "cfg3_recipe"):
+    if name in ("cfg2_recipe", "cfg3_recipe", "cfg2_recipe_s135"):
         # SURVEY section 8d's input recipe exactly as bench.py generates it: texture() (blurred PCG64 noise + 8 blobs),
         # translation (1.7,-1.1,0.6) + 1.5 degree rotation about z, moving = the path's own cubic compensation warp of
         # fixed by -flow with fixed as the out-of-bounds fill (imregister_wrapper, core/optical_flow_3d.py:22-74).
@@ -161,9 +161,10 @@ def fullsize_case(name, warp=None):
         # volume on a sample instead of by checksum).
         if warp is None:
             raise ValueError("recipe cases need the imregister_wrapper to generate the moving volume with")
-        n = 256 if name == "cfg2_recipe" else 512
+        # "_s135": the largest motion of bench.py's synthetic series (time points scale the field by sin(2 pi t/64) + 0.35)
+        n = 512 if name == "cfg3_recipe" else 256
         fixed = texture((n, n, n), seed=1234)
-        gt = flow_gt((n, n, n))
+        gt = flow_gt((n, n, n), scale=1.35 if name.endswith("_s135") else 1.0)
         moving = np.asarray(warp(fixed, -gt[..., 0], -gt[..., 1], -gt[..., 2], fixed), dtype=np.float32).reshape(fixed.shape)
         return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=4 if n == 256 else 5)
     if name == "cfg5_levels8":

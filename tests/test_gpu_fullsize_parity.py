@@ -12,13 +12,16 @@ is compared on the sample.
 Cases
   cfg2_recipe, cfg3_recipe   the inputs bench.py times: SURVEY section 8d's recipe (blurred PCG64 noise + 8 blobs,
                              translation (1.7,-1.1,0.6) + 1.5 degree rotation about z, cubic backward warp)
+  cfg2_recipe_s135           the same at 1.35x the motion: the largest time point of bench.py's synthetic series
   cfg2, cfg3                 the O(N) stand-in inputs of round 2 (periodic texture, pure translation)
   cfg2_asmooth05             config 2's stand-in volume with get_displacement's own default a_smooth = 0.5 (psi_smooth path)
   cfg5                       256x512x512, two channels, 13-level pyramid
   cfg5_levels8               the survey's own config-5 schedule (levels=8: 9 solves)
 
-AUTO resolves to fp32 solver storage with fp64 update arithmetic up to 2^25 voxels (256^3), to packed 42-bit storage
-for larger single-channel volumes (512^3) and to fp64 storage for several channels (config 5).
+AUTO resolves to packed 42-bit solver storage for single-channel volumes above 2^22 voxels (256^3 and 512^3 here; fp32
+storage with fp64 update arithmetic below) and to fp64 storage for several channels (config 5).  The fp32-storage mode
+-- the one SURVEY 8d's 76 B / update figure is defined on, timed by bench.py beside the default -- is measured too:
+8.6e-5 at 256^3 on the recipe inputs (inside the bound, by 10 %), 1.5e-4 at 512^3 (outside).
 
 Tolerance: mean end-point error < 1e-4 voxels (BASELINE.json north_star) on the lattice, its interior and the block for
 the single-channel cases.  CONFIG 5 DOES NOT MEET 1e-4: the GPU measures 2.8e-4 (13 levels); the test pins that measured
@@ -70,7 +73,7 @@ def _epe(a, b):
 
 def _auto_mode(shape, channels, a_smooth):
     nvox = int(np.prod(shape[:3]))
-    m = 2 if channels >= 2 else (3 if nvox > (1 << 25) else 1)
+    m = 2 if channels >= 2 else (3 if nvox > (1 << 22) else 1)
     return 2 if (m == 3 and a_smooth != 1.0) else m
 
 
@@ -95,7 +98,7 @@ def _measure(case, solver_fp64=None):
     g, meta = _load(case)
     fixed, moving, gt, kw = fullsize_case(case, warp=fr.imregister_wrapper)
     assert list(fixed.shape[:3]) == meta["shape_zyx"]
-    if case.endswith("_recipe"):
+    if "_recipe" in case:
         # the moving volume comes out of the engine's own cubic warp here and out of the CPU oracle's in the fixture: the
         # fixed volume by checksum, the moving volume on the lattice to the last float32 bits
         assert hashlib.sha256(np.ascontiguousarray(fixed).tobytes()).hexdigest() == meta["fixed_sha256"]
@@ -132,7 +135,8 @@ def _measure(case, solver_fp64=None):
     return entry, msg
 
 
-@pytest.mark.parametrize("case", ["cfg2_recipe", "cfg2", "cfg2_asmooth05", "cfg3_recipe", "cfg3", "cfg5", "cfg5_levels8"])
+@pytest.mark.parametrize("case", ["cfg2_recipe", "cfg2_recipe_s135", "cfg2", "cfg2_asmooth05", "cfg3_recipe", "cfg3", "cfg5",
+                                  "cfg5_levels8"])
 def test_fullsize_flow_matches_oracle_sample(hip, case):
     e, msg = _measure(case)
     tol = CFG5_PINNED if case.startswith("cfg5") else TOL_MEAN
@@ -142,11 +146,13 @@ def test_fullsize_flow_matches_oracle_sample(hip, case):
     assert abs(e["gpu_vs_ground_truth"] - e["cpu_vs_ground_truth"]) < 1e-3 * max(1.0, e["cpu_vs_ground_truth"]), msg
 
 
-@pytest.mark.parametrize("case,mode,lo,hi", [("cfg3", 1, 5e-5, 2e-4), ("cfg3", 2, 0.0, 3e-5)])
-def test_cfg3_other_storage_modes_are_measured_and_stated(hip, case, mode, lo, hi):
-    """512^3 in the two storage modes AUTO does not pick there, both timed by bench.py beside the packed mode:
-    fp32 storage (solver_fp64=1, the mode SURVEY 8d's 76 B / update figure is defined on) measures 1.5e-4 -- ABOVE the 1e-4
-    bound; increments, frozen system and factors each cost about 1e-4 at this size when held in fp32
-    (profiles/r02/numerics_512_rounding_groups.md) -- and fp64 storage 1.2e-5.  The test pins the measured levels."""
+@pytest.mark.parametrize("case,mode,lo,hi", [("cfg3", 1, 5e-5, 2e-4), ("cfg3", 2, 0.0, 3e-5), ("cfg2_recipe", 1, 3e-5, 1e-4),
+                                              ("cfg2_recipe_s135", 1, 3e-5, 1.5e-4), ("cfg2_recipe", 2, 0.0, 3e-5)])
+def test_other_storage_modes_are_measured_and_stated(hip, case, mode, lo, hi):
+    """The storage modes AUTO does not pick, timed by bench.py beside the packed mode.  fp32 storage (solver_fp64=1, the
+    mode SURVEY 8d's 76 B / update figure is defined on): 8.6e-5 at 256^3 on the recipe inputs (lattice mean; the central
+    block measures 1.03e-4) and 1.5e-4 at 512^3 -- ABOVE the 1e-4 bound; increments, frozen system and factors each cost
+    about 1e-4 at that size when held in fp32 (profiles/r02/numerics_512_rounding_groups.md).  fp64 storage: ~1e-5.
+    The test pins the measured levels."""
     e, msg = _measure(case, solver_fp64=mode)
     assert lo <= e["lattice_mean_epe"] < hi, msg
