@@ -830,11 +830,13 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
 //    8.6e-5 at 256^3 on the benchmark's own input recipe -- inside the bound by 10 %, too thin for a default -- and
 //    1.5e-4 at 512^3: increments, frozen system and factors each cost ~1e-4 there when held in fp32
 //    (profiles/r02/numerics_512_rounding_groups.md);
-//  * several channels: fp64 storage, the reference iteration itself amplifies rounding there.
+//  * several channels: the reference iteration itself amplifies rounding there (config 5, 256x512x512, two channels:
+//    2.8e-4 with fp64 storage AND with packed storage, which is 1.4x faster): packed storage above 2^22 voxels like
+//    one channel, fp64 storage below.
 static int solver_mode(const fr3d_params &p, int C, long long nvox)
 {
     int m = p.solver_fp64;
-    if (m < 0) m = C >= 2 ? 2 : (nvox > (1LL << 22) ? 3 : 1);
+    if (m < 0) m = nvox > (1LL << 22) ? 3 : (C >= 2 ? 2 : 1);
     // packed 42-bit storage exists for the a_smooth == 1 sweep; the psi_smooth solver takes fp64 storage instead
     if (m == 3 && p.a_smooth != 1.0) m = 2;
     return m;
