@@ -171,8 +171,7 @@ def test_cfg4_as_stated_two_ranks_windows_and_device_payload(hip, tmp_path):
             want = np.array([1.7, -1.1, 0.6]) * (0.6 + 0.1 * t)
             # interior mean (the faces the shifted volume has left are cropped); consecutive time points differ by 0.17 in
             # x, so this identifies the time point; rank 0's first volume is checked bit for bit below
-            assert np.abs(g["mean_flow"][q] - want).max() < 0.085,  # half the spacing between time points
-                    (t, g["mean_flow"][q], want)
+            assert np.abs(g["mean_flow"][q] - want).max() < 0.085, (t, g["mean_flow"][q], want)  # half the spacing
     fixed, moving, _ = fast_pair((n, n, n), shift=(1.7 * 0.6, -1.1 * 0.6, 0.6 * 0.6))
     single = fr.get_displacement(fixed, moving, **dict(SOLVER_DEFAULTS, levels=4)).astype(np.float32)
     assert np.array_equal(np.load(out + "_0.npz")["flow0"], single[::8, ::8, ::8])
