@@ -192,6 +192,8 @@ def sweep_source_hash():
 def resolved_mode(solver_fp64, nvox, channels=1, a_smooth=1.0):
     """FR3D_SOLVER_AUTO as the engine resolves it (flowreg3d_amd/csrc/engine.hip: solver_mode)."""
     m = solver_fp64
+    if m < 0 and a_smooth != 1.0:
+        m = 2 if (channels >= 2 or nvox > (1 << 25)) else 1
     if m < 0:
         m = 3 if nvox > (1 << 22) else (2 if channels >= 2 else 1)
     return 2 if (m == 3 and a_smooth != 1.0) else m

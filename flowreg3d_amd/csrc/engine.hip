@@ -836,6 +836,9 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
 static int solver_mode(const fr3d_params &p, int C, long long nvox)
 {
     int m = p.solver_fp64;
+    // the psi_smooth solver (a_smooth != 1) has no packed form and is less sensitive: fp32 storage measures 1.6e-5 at
+    // 256^3 (tests/golden/fullsize_cfg2_asmooth05.npz); fp64 storage above 2^25 voxels and for several channels
+    if (m < 0 && p.a_smooth != 1.0) m = (C >= 2 || nvox > (1LL << 25)) ? 2 : 1;
     if (m < 0) m = nvox > (1LL << 22) ? 3 : (C >= 2 ? 2 : 1);
     // packed 42-bit storage exists for the a_smooth == 1 sweep; the psi_smooth solver takes fp64 storage instead
     if (m == 3 && p.a_smooth != 1.0) m = 2;

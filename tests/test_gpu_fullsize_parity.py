@@ -73,8 +73,9 @@ def _epe(a, b):
 
 def _auto_mode(shape, channels, a_smooth):
     nvox = int(np.prod(shape[:3]))
-    m = 3 if nvox > (1 << 22) else (2 if channels >= 2 else 1)
-    return 2 if (m == 3 and a_smooth != 1.0) else m
+    if a_smooth != 1.0:
+        return 2 if (channels >= 2 or nvox > (1 << 25)) else 1
+    return 3 if nvox > (1 << 22) else (2 if channels >= 2 else 1)
 
 
 def _record(entry):
