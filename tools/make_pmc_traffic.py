@@ -40,7 +40,7 @@ def main():
         head = "?"
     out["_taken_at"] = f"round {tag.lstrip('r0') or '?'}, sources as of commit {head or '?'}"
     out["_sweep_source_hash"] = bench.sweep_source_hash()  # bench.py quotes the record only for these kernel sources
-    for wl, mode in (("cfg2", 1), ("cfg3", 3), ("cfg3", 1), ("cfg3", 2)):
+    for wl, mode in (("cfg2", 3), ("cfg2", 1), ("cfg3", 3), ("cfg3", 1), ("cfg3", 2)):
         pf = os.path.join(ROOT, "profiles", f"{tag}_pmc_fetch_{wl}_m{mode}.txt")
         pw = os.path.join(ROOT, "profiles", f"{tag}_pmc_write_{wl}_m{mode}.txt")
         if not (os.path.exists(pf) and os.path.exists(pw)):
