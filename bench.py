@@ -290,6 +290,10 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
     elapsed = time.perf_counter() - t0
     stats = _lib.prof_get()
     lib.fr3d_prof_enable(0)
+    ran = int(lib.fr3d_last_solver_mode())  # what the library actually resolved FR3D_SOLVER_AUTO to
+    if ran != mode:
+        print(f"note: solver mode {ran} ran where bench.py expected {mode} (memory-driven fallback?)", file=sys.stderr)
+        mode = ran
     per_rank = None
     if world > 1:
         every = [None] * world

@@ -845,12 +845,14 @@ static int solver_mode(const fr3d_params &p, int C, long long nvox)
     return m;
 }
 
+static int resolve_mode(const fr3d_params &p, int C, int Z, int Y, int X, const std::vector<Level> &lv);
+
 static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std::vector<Level> &lv, int min_level,
                                   const RefPyramid &rp, int nb, const float *const *moving, int Z, int Y, int X,
                                   int C, const float *uvw_init, float *const *flow_out, int reserve_nb = 1)
 {
     fr3d_params p = p_in;
-    p.solver_fp64 = solver_mode(p_in, C, (long long)Z * Y * X);
+    p.solver_fp64 = resolve_mode(p_in, C, Z, Y, X, lv);
     FR3D_CHECK(p.solver_fp64 >= 0 && p.solver_fp64 <= 3, "solver_fp64 must be FR3D_SOLVER_AUTO, 0, 1, 2 or 3");
     if (p.solver_fp64 == 3)
         get_displacement_core_t<pk42>(e, p, lv, min_level, rp, nb, moving, Z, Y, X, C, uvw_init, flow_out, reserve_nb);
@@ -874,38 +876,65 @@ static int batch_wanted()
     return g_batch_hint > 0 ? g_batch_hint : (env ? std::max(1, atoi(env)) : 8);
 }
 
+// Bytes one volume of a lock-step batch holds on the finest level with `bytes` per stored solver value, and the HBM
+// the solver slabs may occupy right now.
+static double solver_bytes_per_volume(const std::vector<Level> &lv, int C, double bytes, bool fast_path)
+{
+    const Level &F = lv.back();
+    std::vector<long long> pb;
+    std::vector<int> cp;
+    const double total = (double)make_compact_tables(F.z, F.y, F.x, pb, cp);  // packed rows: 1.1-1.3x the voxel count
+    const double nfin = (double)F.z * F.y * F.x;
+    // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
+    return total * bytes * (12.0 * C + 9.0 + 6.0 + (fast_path ? 0.0 : 13.0)) + nfin * 4.0 * 9.0;
+}
+static double solver_budget(const std::vector<Level> &lv, int C)
+{
+    const Level &F = lv.back();
+    const double nfin = (double)F.z * F.y * F.x;
+    // volume-independent scratch of the finest level: moving level and its warp (2C), fp64 spline coefficients and
+    // the y-pass scratch (~4.2), increments and their median (6), reference and weight pyramids (~4C)
+    const double scratch = nfin * 4.0 * (2.0 * C + 4.2 + 6.0 + 4.0 * C);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return -1.0;
+    // what the solver slabs may occupy: the memory that is free now plus what the engine already
+    // holds (its buffers are reused), minus a margin for the per-level scratch; never more than
+    // 85 % of the device.  Memory the caller holds (a resident series, torch tensors) is respected.
+    // (the host-staging windows "stg*" of fr3d_process_batch_raw stay in use during the call: not reusable)
+    size_t held = 0;
+    for (const auto &kv : g_eng.bufs)
+        if (kv.first.compare(0, 3, "stg") != 0) held += kv.second.cap;
+    const double avail = (double)free_b + (double)held - scratch - 2.0 * 1073741824.0;
+    return std::min(0.85 * (double)total_b, avail);
+}
+
+static int g_last_mode = -1;  // fr3d_last_solver_mode()
+
+// The solver mode of a call: solver_mode(), except that an AUTOMATIC choice of packed storage falls back to fp32
+// storage when one volume's packed slabs do not fit the device and its fp32 slabs do (one 1024^3 volume: 164 GB of
+// packed slabs against 123 GB) -- a volume that size is solved rather than refused; fr3d_last_solver_mode() tells.
+static int resolve_mode(const fr3d_params &p, int C, int Z, int Y, int X, const std::vector<Level> &lv)
+{
+    int m = solver_mode(p, C, (long long)Z * Y * X);
+    if (p.solver_fp64 < 0 && m == 3) {
+        const double budget = solver_budget(lv, C);
+        if (budget > 0 && solver_bytes_per_volume(lv, C, 16.0 / 3.0, true) > budget &&
+            solver_bytes_per_volume(lv, C, 4.0, true) <= budget)
+            m = 1;
+    }
+    g_last_mode = m;
+    return m;
+}
+
 static int pick_batch(int T, const std::vector<Level> &lv, int C)
 {
     int want = batch_wanted();
     if (want > T) want = T;
     if (want < 1) want = 1;
-    const Level &F = lv.back();
-    Skew sk = make_skew(F.z, F.y, F.x);
-    {   // packed rows: 1.1-1.3x the voxel count
-        std::vector<long long> pb;
-        std::vector<int> cp;
-        sk.total = make_compact_tables(F.z, F.y, F.x, pb, cp);
-    }
-    const double nfin = (double)F.z * F.y * F.x;
-    // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
-    const double per_vol = (double)sk.total * g_storage_bytes * (12.0 * C + 9.0 + 6.0 + (g_fast_path ? 0.0 : 13.0)) + nfin * 4.0 * 9.0;
-    // volume-independent scratch of the finest level: moving
-    // level and its warp (2C), fp64 spline coefficients and the y-pass scratch (~4.2), increments and their median (6),
-    // reference and weight pyramids (~4C)
-    const double scratch = nfin * 4.0 * (2.0 * C + 4.2 + 6.0 + 4.0 * C);
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        // what the solver slabs may occupy: the memory that is free now plus what the engine already
-        // holds (its buffers are reused), minus a margin for the per-level scratch; never more than
-        // 85 % of the device.  Memory the caller holds (a resident series, torch tensors) is respected.
-        // (the host-staging windows "stg*" of fr3d_process_batch_raw stay in use during the call: not reusable)
-        size_t held = 0;
-        for (const auto &kv : g_eng.bufs)
-            if (kv.first.compare(0, 3, "stg") != 0) held += kv.second.cap;
-        const double avail = (double)free_b + (double)held - scratch - 2.0 * 1073741824.0;
-        const double budget = std::min(0.85 * (double)total_b, avail);
+    const double per_vol = solver_bytes_per_volume(lv, C, g_storage_bytes, g_fast_path);
+    const double budget = solver_budget(lv, C);
+    if (budget > 0)
         while (want > 1 && per_vol * want > budget) want--;
-    }
     return want;
 }
 
@@ -1032,7 +1061,7 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     const RefPyramid &rp = rp_in ? *rp_in : rp_own;
     const size_t nv = (size_t)Z * Y * X;
     {
-        const int m = solver_mode(*p, C, (long long)Z * Y * X);
+        const int m = resolve_mode(*p, C, Z, Y, X, lv);
         g_storage_bytes = m == 2 ? 8.0 : (m == 3 ? 16.0 / 3.0 : 4.0);
     }
     g_fast_path = p->a_smooth == 1.0;
@@ -1273,6 +1302,8 @@ const char *fr3d_device_info(void)
     info = buf;
     return info.c_str();
 }
+
+int fr3d_last_solver_mode(void) { return g_last_mode; }
 
 int fr3d_set_batch(int nvol)
 {

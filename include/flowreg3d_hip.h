@@ -63,6 +63,11 @@ typedef struct fr3d_params {
 } fr3d_params;
 #define FR3D_SOLVER_AUTO (-1)
 
+/* The solver mode (0..3) the most recent flow solve of this process ran in: what FR3D_SOLVER_AUTO resolved to.  An
+ * automatic choice of packed storage falls back to fp32 storage when one volume's packed solver slabs do not fit the
+ * device's free memory and the fp32 slabs do.  -1 before the first solve. */
+int fr3d_last_solver_mode(void);
+
 /* ---- lifetime ------------------------------------------------------------------------- */
 int fr3d_init(int device);              /* hipSetDevice + stream + workspace; idempotent */
 void fr3d_shutdown(void);               /* frees every device buffer and the stream */

@@ -130,3 +130,26 @@ def test_packed42_falls_back_to_fp64_storage_for_a_smooth(hip):
     a = hip.get_displacement(g["fixed"], g["moving"], solver_fp64=3, **kw)
     b = hip.get_displacement(g["fixed"], g["moving"], solver_fp64=2, **kw)
     assert np.array_equal(a, b)
+
+
+def test_automatic_solver_mode_by_size_and_channels(hip):
+    """FR3D_SOLVER_AUTO as documented in include/flowreg3d_hip.h, read back through fr3d_last_solver_mode():
+    fp32 storage (1) for one channel up to 2^22 voxels, fp64 storage (2) for several channels there, packed 42-bit
+    storage (3) above 2^22 voxels; a_smooth != 1 has no packed form (fp32 storage up to 2^25 voxels)."""
+    from flowreg3d_amd import _lib
+    from flowreg3d_amd.synthetic import fast_pair, make_pair
+    lib = _lib.init(0)
+    kw = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=4, min_level=0, levels=1, eta=0.8, a_data=0.45)
+    f, m, _ = make_pair((20, 24, 28), seed=2)
+    hip.get_displacement(f, m, a_smooth=1.0, **kw)
+    assert lib.fr3d_last_solver_mode() == 1
+    f2, m2, _ = make_pair((20, 24, 28), seed=2, channels=2)
+    hip.get_displacement(f2, m2, a_smooth=1.0, **kw)
+    assert lib.fr3d_last_solver_mode() == 2
+    fb, mb, _ = fast_pair((130, 180, 180))  # 4.2 M voxels > 2^22
+    hip.get_displacement(fb, mb, a_smooth=1.0, **kw)
+    assert lib.fr3d_last_solver_mode() == 3
+    hip.get_displacement(fb, mb, a_smooth=0.5, **kw)
+    assert lib.fr3d_last_solver_mode() == 1
+    hip.get_displacement(f, m, a_smooth=1.0, solver_fp64=2, **kw)
+    assert lib.fr3d_last_solver_mode() == 2
