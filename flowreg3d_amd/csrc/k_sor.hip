@@ -86,10 +86,10 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
     const long long c0 = b0 + jj;
     const int d1 = jm0 - sk_jm(X, r - 1), d2 = jm0 - sk_jm(X, r + 1);
     S *const D = a.d + vol * a.vsD;
-    const long long xm = i > 0 ? bm + jj + d1 : c0;
-    const long long xp = i < X - 1 ? bp + jj + d2 : c0;
-    const long long ym = j > 0 ? bm + jj + d1 - 1 : c0;
-    const long long yp = j < Y - 1 ? bp + jj + d2 + 1 : c0;
+    [[maybe_unused]] const long long xm = i > 0 ? bm + jj + d1 : c0;
+    [[maybe_unused]] const long long xp = i < X - 1 ? bp + jj + d2 : c0;
+    [[maybe_unused]] const long long ym = j > 0 ? bm + jj + d1 - 1 : c0;
+    [[maybe_unused]] const long long yp = j < Y - 1 ? bp + jj + d2 + 1 : c0;
     const long long zm = k > 0 ? bzm + jj : c0;
     const long long zp = k < Z - 1 ? bzp + jj : c0;
     const bool upd = (t % a.update_lag) == 0;
@@ -127,21 +127,73 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
     const R su_x = (R)qxm.v[0] + (R)qxp.v[0], sv_x = (R)qxm.v[1] + (R)qxp.v[1], sw_x = (R)qxm.v[2] + (R)qxp.v[2];
     const R su_y = (R)qym.v[0] + (R)qyp.v[0], sv_y = (R)qym.v[1] + (R)qyp.v[1], sw_y = (R)qym.v[2] + (R)qyp.v[2];
     const R su_z = (R)qzm.v[0] + (R)qzp.v[0], sv_z = (R)qzm.v[1] + (R)qzp.v[1], sw_z = (R)qzm.v[2] + (R)qzp.v[2];
+#ifdef FR3D_EXPERIMENTS
+    if (a.dbg & 16) {
+        const R tiny = (R)1e-30;
+        du1 = du0 + tiny * (su_x + su_y + su_z + m[0] + m[3] + m[6]);
+        dv1 = dv0 + tiny * (sv_x + sv_y + sv_z + m[1] + m[4] + m[7]);
+        dw1 = dw0 + tiny * (sw_x + sw_y + sw_z + m[2] + m[5] + m[8]);
+    } else
+#endif
     sor_relax_sel<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,
                      dw1);
     } else {
     // All seven increment records are requested before anything else; a psi-update wave adds its factor loads
     // behind them.
     const Rec<S, 3> q0 = ldrec<S, 3>(D, c0);
-    const Rec<S, 3> qxm = ldrec<S, 3>(D, xm), qxp = ldrec<S, 3>(D, xp);
-    const Rec<S, 3> qym = ldrec<S, 3>(D, ym), qyp = ldrec<S, 3>(D, yp);
-    const Rec<S, 3> qzm = ldrec<S, 3>(D, zm), qzp = ldrec<S, 3>(D, zp);
+    // Lane-shared neighbour rows (fp64 storage): (k,j,i-1) and (k,j-1,i) are records jj+d1 and jj+d1-1 of the SAME row
+    // (s-1,k), (k,j,i+1) and (k,j+1,i) records jj+d2 and jj+d2+1 of row (s+1,k).  Each of the two rows is loaded once
+    // per lane and the y-neighbour is the adjacent lane's x-neighbour (ds_bpermute; the active lanes of a wave are a
+    // prefix: lane 0 and the last active lane fetch their missing record themselves): 5 wave-wide record loads instead
+    // of 7.  The bytes that cross the fabric are the same; with 24-B records it measures +7.5 % at 512^3 (0.485 ->
+    // 0.522), with 12-B records -6...-10 % and with packed 16-B records nothing (profiles/r03/sor_lane_share_ab.txt),
+    // so only S = double takes it.
+#ifdef FR3D_SOR_SHFL
+    constexpr bool lane_share = FR3D_SOR_SHFL != 0;
+#else
+    constexpr bool lane_share = std::is_same<S, double>::value;
+#endif
+    Rec<S, 3> qxm, qxp, qym, qyp, qzm, qzp;
+    if constexpr (lane_share) {
+        // unconditional row loads: lanes whose neighbour does not exist read a record they do not use -- kept inside the slab
+        const long long lastrec = a.sk.total - 1;
+        auto inslab = [&](long long v) { return v < 0 ? 0LL : (v > lastrec ? lastrec : v); };
+        const Rec<S, 3> rowm = ldrec<S, 3>(D, inslab(bm + jj + d1)), rowp = ldrec<S, 3>(D, inslab(bp + jj + d2));
+        qzm = ldrec<S, 3>(D, zm);
+        qzp = ldrec<S, 3>(D, zp);
+        const unsigned long long act = __ballot(1);
+        const int lane = (int)threadIdx.x;
+        const bool last = ((act >> lane) >> 1) == 0;  // no active lane above this one
+        Rec<S, 3> edge_m = q0, edge_p = q0;
+        if (lane == 0 && j > 0) edge_m = ldrec<S, 3>(D, bm + jj + d1 - 1);
+        if (last && j < Y - 1) edge_p = ldrec<S, 3>(D, bp + jj + d2 + 1);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const typename Sto<S>::val up = __shfl_up(rowm.v[q], 1), dn = __shfl_down(rowp.v[q], 1);
+            qxm.v[q] = i > 0 ? rowm.v[q] : q0.v[q];
+            qxp.v[q] = i < X - 1 ? rowp.v[q] : q0.v[q];
+            qym.v[q] = j > 0 ? (lane == 0 ? edge_m.v[q] : up) : q0.v[q];
+            qyp.v[q] = j < Y - 1 ? (last ? edge_p.v[q] : dn) : q0.v[q];
+        }
+    } else {
+        qxm = ldrec<S, 3>(D, xm); qxp = ldrec<S, 3>(D, xp);
+        qym = ldrec<S, 3>(D, ym); qyp = ldrec<S, 3>(D, yp);
+        qzm = ldrec<S, 3>(D, zm); qzp = ldrec<S, 3>(D, zp);
+    }
     const R du0 = (R)q0.v[0], dv0 = (R)q0.v[1], dw0 = (R)q0.v[2];
     const R su_x = (R)qxm.v[0] + (R)qxp.v[0], sv_x = (R)qxm.v[1] + (R)qxp.v[1], sw_x = (R)qxm.v[2] + (R)qxp.v[2];
     const R su_y = (R)qym.v[0] + (R)qyp.v[0], sv_y = (R)qym.v[1] + (R)qyp.v[1], sw_y = (R)qym.v[2] + (R)qyp.v[2];
     const R su_z = (R)qzm.v[0] + (R)qzp.v[0], sv_z = (R)qzm.v[1] + (R)qzp.v[1], sw_z = (R)qzm.v[2] + (R)qzp.v[2];
     R m[9];
     sor_system<R, S, C>(a, upd, true, vol * a.vsM, vol * a.vsA, vol * a.vsL, c0, du0, dv0, dw0, m);
+#ifdef FR3D_EXPERIMENTS
+    if (a.dbg & 16) {  // memory skeleton: every load and store of the update, none of its arithmetic (results are garbage)
+        const R tiny = (R)1e-30;
+        du1 = du0 + tiny * (su_x + su_y + su_z + m[0] + m[3] + m[6]);
+        dv1 = dv0 + tiny * (sv_x + sv_y + sv_z + m[1] + m[4] + m[7]);
+        dw1 = dw0 + tiny * (sw_x + sw_y + sw_z + m[2] + m[5] + m[8]);
+    } else
+#endif
     sor_relax<R>(m, a.ax, a.ay, a.az, su_x, sv_x, sw_x, su_y, sv_y, sw_y, su_z, sv_z, sw_z, du0, dv0, dw0, du1, dv1,
                  dw1);
     }

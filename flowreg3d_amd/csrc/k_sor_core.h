@@ -146,6 +146,10 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
                 }
                 // fp32 powf (~1 ulp) with fp32 storage: the products below are stored in fp32 anyway, and the fp64
                 // pow's ~600-instruction dependent chain set a ~6 us latency floor on every launch
+#ifdef FR3D_EXPERIMENTS
+                if (a.dbg & 32) wt *= adc * (val + 1e-6);  // timing experiment: psi without the pow
+                else
+#endif
                 if (Sto<S>::wide) wt *= adc * pow(val + 1e-6, adc - 1.0);  // reference-grade modes
                 else wt *= adc * (double)powf((float)(val + 1e-6), (float)(adc - 1.0));
             }
