@@ -195,7 +195,7 @@ def resolved_mode(solver_fp64, nvox, channels=1, a_smooth=1.0):
     if m < 0 and a_smooth != 1.0:
         m = 2 if (channels >= 2 or nvox > (1 << 25)) else 1
     if m < 0:
-        m = 3 if nvox > (1 << 22) else (2 if channels >= 2 else 1)
+        m = 2 if channels >= 2 else (3 if nvox > (1 << 22) else 1)
     return 2 if (m == 3 and a_smooth != 1.0) else m
 
 

@@ -85,8 +85,8 @@ def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=2
 
     fixed/moving are used by the reference only through the fp32 resampler
     (util/resize_util_3D.py:116), and uvw/weight likewise, so they cross the ABI as float32.
-    ``solver_fp64`` is an extension (fr3d_params.solver_fp64): None = automatic (packed 42-bit solver storage above 2^22
-    voxels; below: fp32 storage with fp64 update arithmetic for one channel, fp64 storage for several),
+    ``solver_fp64`` is an extension (fr3d_params.solver_fp64): None = automatic (one channel: fp32 solver storage
+    with fp64 update arithmetic up to 2^22 voxels, packed 42-bit storage above; several channels: fp64 storage),
     0 / 1 / 2 / 3 force fp32 / fp64 arithmetic on fp32 storage / fp64 storage / packed 42-bit storage.
     """
     fixed = np.asarray(fixed)

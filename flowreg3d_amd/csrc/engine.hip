@@ -653,6 +653,34 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         }
         // increments back to the natural layout, 5^3 median (:517-526), accumulate (:527-529)
         const bool med = std::min(lz, std::min(ly, lx)) > 5;
+        if constexpr (!std::is_same<S, float>::value) {
+            // fp64 / packed storage: the level tail as the reference evaluates it -- fp64 increments, fp64 median,
+            // u + du in fp64, ONE rounding to the fp32 the next level's resampler and warp read (exact_tail below)
+            for (int b = 0; b < nb; b++) {
+                double *dn = e.f64("d_nat64", nl * 3);
+                float **u = &uvw[3 * b];
+                {
+                    Span sp(e, FR3D_K_OTHER, 0, 0, 0);
+                    launch_unskew_unpack<S, double>(e.st, dbuf + (size_t)b * a.vsD, dn, (long long)nl, 3, sk);
+                }
+                if (med && median_can_accumulate(lz, ly, lx)) {
+                    Span sp(e, FR3D_K_MEDIAN, 28.0 * nl * 3, 2, (long long)nl * 3);
+                    launch_median5_fields_f64(e.st, dn, (long long)nl, lz, ly, lx, e.f32("d_nat", nl * 3), u);
+                    continue;
+                }
+                double *dm = med ? e.f64("d_med64", nl) : nullptr;
+                for (int d = 0; d < 3; d++) {
+                    const double *inc = dn + (size_t)d * nl;
+                    if (med) {  // levels too small for the tiled kernels: one thread per voxel, fp64 selection
+                        Span sp(e, FR3D_K_MEDIAN, 16.0 * nl, 1, (long long)nl);
+                        launch_median5_f64(e.st, inc, lz, ly, lx, dm);
+                        inc = dm;
+                    }
+                    Span sp(e, FR3D_K_OTHER, 0, 0, 0);
+                    launch_accum_round_once(e.st, u[d], inc, (long long)nl);
+                }
+            }
+        } else
         for (int b = 0; b < nb; b++) {
             float *dn = e.f32("d_nat", nl * 3);
             float **u = &uvw[3 * b];
@@ -792,6 +820,17 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
         // :517-529 in fp64: increments back to the natural order, 5^3 median, u = u + du
         double *dn = e.f64("vf_dnat", nl * 3);
         launch_unskew_unpack<double, double>(e.st, Drec, dn, (long long)nl, 3, sk);
+#ifdef FR3D_EXPERIMENTS
+        // numerics experiment (which part of the shipped modes' difference is the fp32 level tail?): FR3D_VERIFY_TAIL32=1
+        // rounds the increments to fp32 before the median and keeps the level flow in fp32, like the shipped modes
+        static const char *tail_env = getenv("FR3D_VERIFY_TAIL32");
+        const bool tail32 = tail_env && atoi(tail_env) != 0;
+        if (tail32) {
+            float *tmpf = e.f32("vf_tail32", nl * 3);
+            launch_cast<double, float>(e.st, dn, (long long)nl * 3, tmpf);
+            launch_cast<float, double>(e.st, tmpf, (long long)nl * 3, dn);
+        }
+#endif
         const bool med = std::min(lz, std::min(ly, lx)) > 5;
         double *dm = med ? e.f64("vf_dmed", nl) : nullptr;
         for (int d = 0; d < 3; d++) {
@@ -801,6 +840,13 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
                 inc = dm;
             }
             launch_axpy_f64(e.st, ud[d], inc, (long long)nl);
+#ifdef FR3D_EXPERIMENTS
+            if (tail32) {
+                float *tmpf = e.f32("vf_tail32", nl * 3);
+                launch_cast<double, float>(e.st, ud[d], (long long)nl, tmpf);
+                launch_cast<float, double>(e.st, tmpf, (long long)nl, ud[d]);
+            }
+#endif
         }
         pz = lz; py = ly; px = lx;
     }
@@ -826,20 +872,19 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
 // reference CPU path WITH MARGIN, as measured against full CPU runs (DESIGN.md section 2,
 // tests/test_gpu_fullsize_parity.py, profiles/parity_fullsize.json):
 //  * one channel, up to 2^22 voxels: fp32 storage with fp64 update arithmetic (128^3: ~3e-5);
-//  * one channel, larger volumes: packed 42-bit storage (256^3: 1.9e-5, 512^3: 3.4e-5).  fp32 storage measures
+//  * one channel, larger volumes: packed 42-bit storage (256^3: 1.6e-5, 512^3: 3.2e-5).  fp32 storage measures
 //    8.6e-5 at 256^3 on the benchmark's own input recipe -- inside the bound by 10 %, too thin for a default -- and
-//    1.5e-4 at 512^3: increments, frozen system and factors each cost ~1e-4 there when held in fp32
-//    (profiles/r02/numerics_512_rounding_groups.md);
-//  * several channels: the reference iteration itself amplifies rounding there (config 5, 256x512x512, two channels:
-//    2.8e-4 with fp64 storage AND with packed storage, which is 1.4x faster): packed storage above 2^22 voxels like
-//    one channel, fp64 storage below.
+//    1.5e-4 at 512^3;
+//  * several channels: fp64 storage.  The two-channel iteration amplifies every rounding of the stored operands
+//    (config 5, 256x512x512: 2.5e-4 with packed storage, outside the bound); with fp64 storage and the exact level
+//    tail the flow is within 2e-11 of the CPU path there.
 static int solver_mode(const fr3d_params &p, int C, long long nvox)
 {
     int m = p.solver_fp64;
     // the psi_smooth solver (a_smooth != 1) has no packed form and is less sensitive: fp32 storage measures 1.6e-5 at
     // 256^3 (tests/golden/fullsize_cfg2_asmooth05.npz); fp64 storage above 2^25 voxels and for several channels
     if (m < 0 && p.a_smooth != 1.0) m = (C >= 2 || nvox > (1LL << 25)) ? 2 : 1;
-    if (m < 0) m = nvox > (1LL << 22) ? 3 : (C >= 2 ? 2 : 1);
+    if (m < 0) m = C >= 2 ? 2 : (nvox > (1LL << 22) ? 3 : 1);
     // packed 42-bit storage exists for the a_smooth == 1 sweep; the psi_smooth solver takes fp64 storage instead
     if (m == 3 && p.a_smooth != 1.0) m = 2;
     return m;

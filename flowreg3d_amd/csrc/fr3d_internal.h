@@ -378,6 +378,10 @@ void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float 
 void launch_median5_fields(hipStream_t st, const float *in, long long fstride, int nf, int Z, int Y, int X,
                            float *const *out, bool accumulate);
 bool median_can_accumulate(int Z, int Y, int X);
+// exact level tail of the fp64 / packed solver modes: u[f] = RN32(u[f] + median64(in[f])), three fp64 fields
+void launch_median5_fields_f64(hipStream_t st, const double *in, long long fstride, int Z, int Y, int X, float *v32,
+                               float *const *u);
+void launch_accum_round_once(hipStream_t st, float *u, const double *d, long long n);
 
 // f-1 preprocessing (k_preproc.hip)
 template <typename TIN>

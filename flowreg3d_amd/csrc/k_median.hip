@@ -350,17 +350,20 @@ __device__ __forceinline__ void median_offsets(int z, int y, int Z, int Y, int X
     }
 }
 
+// TIN = double (exact level tail of the fp64 / packed solver modes): the keys are the values ROUNDED to fp32 -- the
+// result is RN32(median), because rounding is monotone -- and k_median5_refine below recovers the fp64 median from it.
+template <typename TIN>
 __global__ void __launch_bounds__(MF_T) __attribute__((amdgpu_waves_per_eu(3, 4)))
-k_median5_flat(const float *__restrict__ in, long long fstride, int Z, int Y, int X, unsigned npairs, MedianDst dst)
+k_median5_flat(const TIN *__restrict__ in, long long fstride, int Z, int Y, int X, unsigned npairs, MedianDst dst)
 {
     __shared__ int sK[2][25][MF_W];  // [column parity][rank][slot]
     const int L = threadIdx.x;
     const int XP = (X + 1) >> 1;
-    const float *__restrict__ src = in + (size_t)blockIdx.y * fstride;
+    const TIN *__restrict__ src = in + (size_t)blockIdx.y * fstride;
     auto sort_store = [&](const unsigned (&zo)[5], const unsigned (&yo)[5], int xm, int par, int slot) {
         int k[32];
 #pragma unroll
-        for (int n = 0; n < 25; n++) k[n] = f2key(src[zo[n / 5] + yo[n % 5] + (unsigned)xm]);
+        for (int n = 0; n < 25; n++) k[n] = f2key((float)src[zo[n / 5] + yo[n % 5] + (unsigned)xm]);
 #pragma unroll
         for (int n = 25; n < 32; n++) k[n] = KEY_PAD;
         OESortI<32, 0, 32>::run(k);
@@ -438,6 +441,97 @@ k_median5_flat(const float *__restrict__ in, long long fstride, int Z, int Y, in
     }
 }
 
+// The fp64 median of a 5^3 window from its fp32 rounding v = RN32(median): the median is the window element x with
+// RN32(x) == v whose rank among those elements is 62 - #{x : RN32(x) < v} -- almost always there is exactly one such
+// element.  One thread per voxel scans its 125 window values (neighbouring lanes read neighbouring addresses; the
+// window lives in L1/L2), then adds the median to the level flow the way the reference does (core/optical_flow_3d.py:
+// 517-529: fp64 median, u = u + du in fp64, rounded to fp32 by the next level's resampler, util/resize_util_3D.py:116):
+// u32 <- RN32(u32 + median64), ONE rounding.  (The fp32 tail -- median of fp32-rounded increments, fp32 add -- rounds
+// twice; the 1-ulp differences that makes in the level flow are amplified by an ill-conditioned iteration to 2.8e-4
+// voxels on BASELINE config 5: DESIGN.md section 2.)
+__global__ void __launch_bounds__(256)
+k_median5_refine(const double *__restrict__ in, const float *__restrict__ v32, long long fstride, int Z, int Y, int X,
+                 MedianDst dst)
+{
+    const long long nvox = (long long)Z * Y * X;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvox) return;
+    const int x = (int)(t % X), y = (int)((t / X) % Y), z = (int)(t / ((long long)X * Y));
+    const double *__restrict__ src = in + (size_t)blockIdx.y * fstride;
+    const float v = v32[(size_t)blockIdx.y * fstride + t];
+    unsigned zo[5], yo[5];
+    median_offsets(z, y, Z, Y, X, zo, yo);
+    int xo[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) xo[q] = mirror2(x + q - 2, X);
+    int lt = 0, ties = 0;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // the first four tied values
+    for (int a = 0; a < 5; a++)
+        for (int b = 0; b < 5; b++) {
+            const double *row = src + zo[a] + yo[b];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const double xv = row[xo[c]];
+                const float f = (float)xv;
+                lt += f < v ? 1 : 0;
+                if (f == v) {
+                    if (ties == 0) t0 = xv;
+                    else if (ties == 1) t1 = xv;
+                    else if (ties == 2) t2 = xv;
+                    else if (ties == 3) t3 = xv;
+                    ties++;
+                }
+            }
+        }
+    const int r = 62 - lt;  // rank of the median among the tied values
+    double m;
+    if (ties <= 0 || r < 0 || r >= ties) {
+        m = (double)v;  // NaN in the window: keep what the fp32 selection produced
+    } else if (ties == 1) {
+        m = t0;
+    } else if (ties <= 4) {
+        const double inf = __longlong_as_double(0x7ff0000000000000LL);
+        double s0 = t0, s1 = t1, s2 = ties > 2 ? t2 : inf, s3 = ties > 3 ? t3 : inf, tmp;
+#define FR3D_CEXD(A, B) { tmp = fmin(A, B); B = fmax(A, B); A = tmp; }
+        FR3D_CEXD(s0, s1) FR3D_CEXD(s2, s3) FR3D_CEXD(s0, s2) FR3D_CEXD(s1, s3) FR3D_CEXD(s1, s2)
+#undef FR3D_CEXD
+        m = r == 0 ? s0 : (r == 1 ? s1 : (r == 2 ? s2 : s3));
+    } else {
+        // many values inside one fp32 interval (flat regions): the r-th smallest of them by counting, O(ties * 125)
+        m = (double)v;
+        for (int a = 0; a < 5; a++)
+            for (int b = 0; b < 5; b++)
+                for (int c = 0; c < 5; c++) {
+                    const double cand = src[zo[a] + yo[b] + xo[c]];
+                    if ((float)cand != v) continue;
+                    int less = 0, eq = 0;
+                    for (int a2 = 0; a2 < 5; a2++)
+                        for (int b2 = 0; b2 < 5; b2++)
+                            for (int c2 = 0; c2 < 5; c2++) {
+                                const double o = src[zo[a2] + yo[b2] + xo[c2]];
+                                if ((float)o != v) continue;
+                                less += o < cand ? 1 : 0;
+                                eq += o == cand ? 1 : 0;
+                            }
+                    if (less <= r && r < less + eq) m = cand;
+                }
+    }
+    float *__restrict__ out = dst.p[blockIdx.y];
+    out[t] = dst.acc ? (float)((double)out[t] + m) : (float)m;
+}
+
+// level flow += increments without a median (levels of at most 5 voxels per axis): the same single rounding
+__global__ void k_accum_round_once(float *__restrict__ u, const double *__restrict__ d, long long n)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) u[t] = (float)((double)u[t] + d[t]);
+}
+void launch_accum_round_once(hipStream_t st, float *u, const double *d, long long n)
+{
+    hipLaunchKernelGGL(k_accum_round_once, dim3(cdiv(n, 256)), dim3(256), 0, st, u, d, n);
+    FR3D_LAUNCH_CHECK();
+}
+
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);
 
 static bool median_flat_ok(int Z, int Y, int X, int nf)
@@ -473,13 +567,34 @@ void launch_median5_fields(hipStream_t st, const float *in, long long fstride, i
         for (int f = 0; f < 3; f++) d.p[f] = f < nf ? out[f] : nullptr;
         d.acc = accumulate ? 1 : 0;
         const unsigned npairs = (unsigned)((long long)Z * Y * ((X + 1) / 2));
-        hipLaunchKernelGGL(k_median5_flat, dim3(cdiv((long long)npairs, MF_T), nf), dim3(MF_T), 0, st, in, fstride, Z, Y, X,
+        hipLaunchKernelGGL(k_median5_flat<float>, dim3(cdiv((long long)npairs, MF_T), nf), dim3(MF_T), 0, st, in, fstride, Z, Y, X,
                            npairs, d);
         FR3D_LAUNCH_CHECK();
         return;
     }
     FR3D_CHECK(!accumulate, "internal: accumulating median needs the flattened kernel");
     for (int f = 0; f < nf; f++) launch_median5(st, in + (size_t)f * fstride, Z, Y, X, out[f]);
+}
+
+// Exact level tail (fp64 / packed solver modes): u[f] = RN32(u[f] + median64(in[f])) for three fp64 fields; `v32` is
+// scratch for 3 * Z*Y*X floats.  Needs median_can_accumulate(Z, Y, X).
+void launch_median5_fields_f64(hipStream_t st, const double *in, long long fstride, int Z, int Y, int X, float *v32,
+                               float *const *u)
+{
+    FR3D_CHECK(median_flat_ok(Z, Y, X, 3), "internal: exact median tail needs the flattened kernel");
+    MedianDst tmp, d;
+    for (int f = 0; f < 3; f++) {
+        tmp.p[f] = v32 + (size_t)f * fstride;
+        d.p[f] = u[f];
+    }
+    tmp.acc = 0;
+    d.acc = 1;
+    const unsigned npairs = (unsigned)((long long)Z * Y * ((X + 1) / 2));
+    hipLaunchKernelGGL(k_median5_flat<double>, dim3(cdiv((long long)npairs, MF_T), 3), dim3(MF_T), 0, st, in, fstride, Z, Y, X,
+                       npairs, tmp);
+    FR3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_median5_refine, dim3(cdiv((long long)Z * Y * X, 256), 3), dim3(256), 0, st, in, v32, fstride, Z, Y, X, d);
+    FR3D_LAUNCH_CHECK();
 }
 
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out)

@@ -644,6 +644,7 @@ template void launch_unskew_unpack<float, float>(hipStream_t, const float *, flo
 template void launch_unskew_unpack<double, float>(hipStream_t, const double *, float *, long long, int, const Skew &);
 template void launch_unskew_unpack<pk42, float>(hipStream_t, const pk42 *, float *, long long, int, const Skew &);
 template void launch_unskew_unpack<double, double>(hipStream_t, const double *, double *, long long, int, const Skew &);
+template void launch_unskew_unpack<pk42, double>(hipStream_t, const pk42 *, double *, long long, int, const Skew &);
 
 // L = ax*(u_ip + u_im - 2u) + ay*(...) + az*(...) with edge-padded u (add_boundary,
 // core/optical_flow_3d.py:88), evaluated in fp64 from the fp32-exact level flow.

@@ -56,9 +56,9 @@ typedef struct fr3d_params {
                                              values per 16 bytes: 31 significant bits for 4/3 of the fp32 bytes),
                                              fp64 arithmetic; a_smooth == 1 sweep only (mode 2 otherwise);
                                           FR3D_SOLVER_AUTO (-1): the cheapest mode measured to stay within
-                                             1e-4 voxels of the reference CPU path with margin -- 3 above 2^22
-                                             voxels, below that 1 for one channel and 2 for several (what the
-                                             Python mirror passes by default) */
+                                             1e-4 voxels of the reference CPU path with margin -- one channel: 1 up
+                                             to 2^22 voxels, 3 above; several channels: 2 (what the Python mirror
+                                             passes by default) */
     int reserved[7];
 } fr3d_params;
 #define FR3D_SOLVER_AUTO (-1)

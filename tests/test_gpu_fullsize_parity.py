@@ -18,16 +18,17 @@ Cases
   cfg5                       256x512x512, two channels, 13-level pyramid
   cfg5_levels8               the survey's own config-5 schedule (levels=8: 9 solves)
 
-AUTO resolves to packed 42-bit solver storage for volumes above 2^22 voxels (every case here; below that: fp32
-storage with fp64 update arithmetic for one channel, fp64 storage for several).  The fp32-storage mode
+AUTO resolves to packed 42-bit solver storage for single-channel volumes above 2^22 voxels (256^3 and 512^3 here; fp32
+storage with fp64 update arithmetic below) and to fp64 storage for several channels (config 5).  The fp32-storage mode
 -- the one SURVEY 8d's 76 B / update figure is defined on, timed by bench.py beside the default -- is measured too:
 8.6e-5 at 256^3 on the recipe inputs (inside the bound, by 10 %), 1.5e-4 at 512^3 (outside).
 
-Tolerance: mean end-point error < 1e-4 voxels (BASELINE.json north_star) on the lattice, its interior and the block for
-the single-channel cases.  CONFIG 5 DOES NOT MEET 1e-4: the GPU measures 2.8e-4 (13 levels); the test pins that measured
-level (< 3.5e-4) and says so -- the same CPU source rebuilt with FMA contraction differs from the committed sample by
-5.98e-4 (profiles/r02/cfg5_oracle_reproducibility.json), i.e. the two-channel reference iteration is itself not
-reproducible to 1e-4 at this size, but that explains the miss, it does not remove it.
+Tolerance: mean end-point error < 1e-4 voxels (BASELINE.json north_star) on the lattice, its interior and the block, for
+EVERY configuration.  Config 5 (two channels) meets it since the level tail is evaluated like the reference's (fp64
+median, one rounding of u + du: k_median.hip k_median5_refine): 2e-11 with fp64 storage -- it measured 2.8e-4 while the
+increments were rounded to fp32 before the median, a double rounding of the level flow that the two-channel iteration
+amplifies.  Packed storage on config 5 measures 2.5e-4 (pinned below): why AUTO takes fp64
+storage for several channels.
 Every run appends its measured figures to gpurun_out/parity_fullsize.json (merged back by gpurun; the committed copy is
 profiles/parity_fullsize.json, which bench.py quotes).
 """
@@ -44,8 +45,6 @@ from conftest import GOLDEN, ROOT
 pytestmark = pytest.mark.gpu
 
 TOL_MEAN = 1e-4
-# measured 2.8e-4 (13 levels) / see the record for levels=8; the north-star bound of 1e-4 is NOT met for config 5
-CFG5_PINNED = 3.5e-4
 SOLVER_MODE_NAMES = {0: "fp32 storage, fp32 arithmetic", 1: "fp32 storage, fp64 arithmetic", 2: "fp64 storage",
                      3: "packed 42-bit storage, fp64 arithmetic"}
 
@@ -75,7 +74,7 @@ def _auto_mode(shape, channels, a_smooth):
     nvox = int(np.prod(shape[:3]))
     if a_smooth != 1.0:
         return 2 if (channels >= 2 or nvox > (1 << 25)) else 1
-    return 3 if nvox > (1 << 22) else (2 if channels >= 2 else 1)
+    return 2 if channels >= 2 else (3 if nvox > (1 << 22) else 1)
 
 
 def _record(entry):
@@ -140,20 +139,22 @@ def _measure(case, solver_fp64=None):
                                   "cfg5_levels8"])
 def test_fullsize_flow_matches_oracle_sample(hip, case):
     e, msg = _measure(case)
-    tol = CFG5_PINNED if case.startswith("cfg5") else TOL_MEAN
+    tol = TOL_MEAN
     assert e["lattice_mean_epe"] < tol and e["block_mean_epe"] < tol and e["interior_lattice_mean_epe"] < tol, msg
     assert e["lattice_max_epe"] < 0.25 and e["block_max_epe"] < 0.05, msg
     # the GPU solves the same problem as the CPU path: same error against the synthetic ground truth
     assert abs(e["gpu_vs_ground_truth"] - e["cpu_vs_ground_truth"]) < 1e-3 * max(1.0, e["cpu_vs_ground_truth"]), msg
 
 
-@pytest.mark.parametrize("case,mode,lo,hi", [("cfg3", 1, 5e-5, 2e-4), ("cfg3", 2, 0.0, 3e-5), ("cfg2_recipe", 1, 3e-5, 1e-4),
-                                              ("cfg2_recipe_s135", 1, 3e-5, 1.5e-4), ("cfg2_recipe", 2, 0.0, 3e-5), ("cfg5", 2, 1e-4, 3.5e-4)])
+@pytest.mark.parametrize("case,mode,lo,hi", [("cfg3", 1, 5e-5, 2e-4), ("cfg3", 2, 0.0, 1e-7), ("cfg2_recipe", 1, 3e-5, 1e-4),
+                                              ("cfg2_recipe_s135", 1, 3e-5, 1.5e-4), ("cfg2_recipe", 2, 0.0, 1e-7),
+                                              ("cfg5", 3, 1e-4, 3.5e-4), ("cfg5_levels8", 3, 3e-5, 1.5e-4)])
 def test_other_storage_modes_are_measured_and_stated(hip, case, mode, lo, hi):
     """The storage modes AUTO does not pick, timed by bench.py beside the packed mode.  fp32 storage (solver_fp64=1, the
     mode SURVEY 8d's 76 B / update figure is defined on): 8.6e-5 at 256^3 on the recipe inputs (lattice mean; the central
     block measures 1.03e-4) and 1.5e-4 at 512^3 -- ABOVE the 1e-4 bound; increments, frozen system and factors each cost
-    about 1e-4 at that size when held in fp32 (profiles/r02/numerics_512_rounding_groups.md).  fp64 storage: ~1e-5.
-    The test pins the measured levels."""
+    about 1e-4 at that size when held in fp32 (profiles/r02/numerics_512_rounding_groups.md).  fp64 storage: 2e-9 ... 4e-9
+    (what is left is the fp32 rounding of the output).  Packed storage on the two-channel config 5: 2.5e-4, outside the
+    bound (AUTO takes fp64 storage there).  The test pins the measured levels."""
     e, msg = _measure(case, solver_fp64=mode)
     assert lo <= e["lattice_mean_epe"] < hi, msg
