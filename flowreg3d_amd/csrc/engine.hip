@@ -653,9 +653,13 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         }
         // increments back to the natural layout, 5^3 median (:517-526), accumulate (:527-529)
         const bool med = std::min(lz, std::min(ly, lx)) > 5;
-        if constexpr (!std::is_same<S, float>::value) {
-            // fp64 / packed storage: the level tail as the reference evaluates it -- fp64 increments, fp64 median,
-            // u + du in fp64, ONE rounding to the fp32 the next level's resampler and warp read (exact_tail below)
+        if constexpr (std::is_same<S, double>::value) {
+            // fp64 storage: the level tail as the reference evaluates it -- fp64 increments, fp64 median, u + du in
+            // fp64, ONE rounding to the fp32 the next level's resampler and warp read (k_median.hip: k_median5_refine).
+            // With it this mode is within 4e-9 voxels of the CPU path at 256^3 / 512^3 and 2e-11 on the two-channel
+            // config 5 (2.8e-4 with the fp32 tail below, whose double rounding of the level flow that iteration
+            // amplifies).  Costs 5 ms per 256^3 volume; packed and fp32 storage keep the fp32 tail: their storage
+            // rounding dominates (packed: 1.9e-5 with either tail).
             for (int b = 0; b < nb; b++) {
                 double *dn = e.f64("d_nat64", nl * 3);
                 float **u = &uvw[3 * b];

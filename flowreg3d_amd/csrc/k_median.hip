@@ -449,75 +449,106 @@ k_median5_flat(const TIN *__restrict__ in, long long fstride, int Z, int Y, int 
 // u32 <- RN32(u32 + median64), ONE rounding.  (The fp32 tail -- median of fp32-rounded increments, fp32 add -- rounds
 // twice; the 1-ulp differences that makes in the level flow are amplified by an ill-conditioned iteration to 2.8e-4
 // voxels on BASELINE config 5: DESIGN.md section 2.)
-__global__ void __launch_bounds__(256)
+#define MR_TX 64
+#define MR_TY 4
+#define MR_ZB 16  // z-slabs a workgroup marches through
+__global__ void __launch_bounds__(MR_TX * MR_TY)
 k_median5_refine(const double *__restrict__ in, const float *__restrict__ v32, long long fstride, int Z, int Y, int X,
-                 MedianDst dst)
+                 int nzb, MedianDst dst, int dbg)
 {
-    const long long nvox = (long long)Z * Y * X;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nvox) return;
-    const int x = (int)(t % X), y = (int)((t / X) % Y), z = (int)(t / ((long long)X * Y));
-    const double *__restrict__ src = in + (size_t)blockIdx.y * fstride;
-    const float v = v32[(size_t)blockIdx.y * fstride + t];
-    unsigned zo[5], yo[5];
-    median_offsets(z, y, Z, Y, X, zo, yo);
-    int xo[5];
+    // A workgroup owns 64 x 4 (x,y) columns and marches along z with a ring of five window slabs in LDS (8 rows x 68
+    // values each, mirror boundary applied while loading): one global read per value and slab, the 125 window reads
+    // of a voxel come from LDS.  (Reading the window straight from global memory cost 1 KB of L2 traffic per voxel:
+    // 15 ms per 256^3 volume instead of 2.)
+    __shared__ double tile[5][MR_TY + 4][MR_TX + 4];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * MR_TX + tx;
+    const int x0 = blockIdx.x * MR_TX, y0 = blockIdx.y * MR_TY;
+    const int x = x0 + tx, y = y0 + ty;
+    const int field = blockIdx.z / nzb, z0 = (blockIdx.z % nzb) * MR_ZB;
+    const double *__restrict__ src = in + (size_t)field * fstride;
+    float *__restrict__ out = dst.p[field];
+    const bool live = x < X && y < Y;
+    auto load_slab = [&](int zs) {
+        const int slot = (zs + 10) % 5;
+        const size_t zb = (size_t)mirror2(zs < -2 ? -2 : (zs > Z + 1 ? Z + 1 : zs), Z) * Y;
+        for (int e = tid; e < (MR_TY + 4) * (MR_TX + 4); e += MR_TX * MR_TY) {
+            const int ry = e / (MR_TX + 4), rx = e % (MR_TX + 4);
+            int yy = y0 - 2 + ry, xx = x0 - 2 + rx;
+            yy = mirror2(yy > Y + 1 ? Y + 1 : yy, Y);  // rows / columns of a partial tile beyond the volume are not used
+            xx = mirror2(xx > X + 1 ? X + 1 : xx, X);
+            tile[slot][ry][rx] = src[(zb + yy) * X + xx];
+        }
+    };
+    for (int q = -2; q < 2; q++) load_slab(z0 + q);
+    for (int z = z0; z < z0 + MR_ZB && z < Z; z++) {
+        load_slab(z + 2);
+        __syncthreads();
+        if (live) {
+            const long long t = ((long long)z * Y + y) * X + x;
+            const float v = v32[(size_t)field * fstride + t];
+            // pass 1, branch-free: how many window values round below v, how many round to v, and the last of those
+            int lt = 0, ties = 0;
+            double hit = 0.0;
+#pragma unroll 1
+            for (int a = 0; a < 5; a++) {
+                const int slot = (z - 2 + a + 10) % 5;
 #pragma unroll
-    for (int q = 0; q < 5; q++) xo[q] = mirror2(x + q - 2, X);
-    int lt = 0, ties = 0;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;  // the first four tied values
-    for (int a = 0; a < 5; a++)
-        for (int b = 0; b < 5; b++) {
-            const double *row = src + zo[a] + yo[b];
+                for (int b = 0; b < 5; b++)
 #pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const double xv = row[xo[c]];
-                const float f = (float)xv;
-                lt += f < v ? 1 : 0;
-                if (f == v) {
-                    if (ties == 0) t0 = xv;
-                    else if (ties == 1) t1 = xv;
-                    else if (ties == 2) t2 = xv;
-                    else if (ties == 3) t3 = xv;
-                    ties++;
+                    for (int c = 0; c < 5; c++) {
+                        const double xv = tile[slot][ty + b][tx + c];
+                        const float f = (float)xv;
+                        lt += f < v ? 1 : 0;
+                        const bool e = f == v;
+                        ties += e ? 1 : 0;
+                        hit = e ? xv : hit;
+                    }
+            }
+            const int r = 62 - lt;  // rank of the median among the values that round to v
+            double m;
+            if (ties == 1) {
+                m = hit;  // the usual case: exactly one window value rounds to v -- it is the median
+            } else if (ties <= 0 || r < 0 || r >= ties || (dbg & 1)) {
+                m = (double)v;  // NaN in the window: keep what the fp32 selection produced (dbg: timing experiment)
+            } else {
+                // several values inside one fp32 interval (flat regions; a few per cent of the voxels of a smooth field):
+                // the r-th smallest of them, one pass per distinct value up to the wanted rank
+                const double inf = __longlong_as_double(0x7ff0000000000000LL);
+                double cur = -inf;
+                int seen = 0;
+                m = (double)v;
+                for (int pass = 0; pass < 125; pass++) {
+                    double nxt = inf;
+                    int cnt = 0;
+                    for (int a = 0; a < 5; a++) {
+                        const int slot = (z - 2 + a + 10) % 5;
+                        for (int b = 0; b < 5; b++)
+#pragma unroll
+                            for (int c = 0; c < 5; c++) {
+                                const double xv = tile[slot][ty + b][tx + c];
+                                if ((float)xv == v && xv > cur) {
+                                    if (xv < nxt) {
+                                        nxt = xv;
+                                        cnt = 1;
+                                    } else if (xv == nxt) {
+                                        cnt++;
+                                    }
+                                }
+                            }
+                    }
+                    if (cnt == 0) break;
+                    if (r < seen + cnt) {
+                        m = nxt;
+                        break;
+                    }
+                    seen += cnt;
+                    cur = nxt;
                 }
             }
+            out[t] = dst.acc ? (float)((double)out[t] + m) : (float)m;
         }
-    const int r = 62 - lt;  // rank of the median among the tied values
-    double m;
-    if (ties <= 0 || r < 0 || r >= ties) {
-        m = (double)v;  // NaN in the window: keep what the fp32 selection produced
-    } else if (ties == 1) {
-        m = t0;
-    } else if (ties <= 4) {
-        const double inf = __longlong_as_double(0x7ff0000000000000LL);
-        double s0 = t0, s1 = t1, s2 = ties > 2 ? t2 : inf, s3 = ties > 3 ? t3 : inf, tmp;
-#define FR3D_CEXD(A, B) { tmp = fmin(A, B); B = fmax(A, B); A = tmp; }
-        FR3D_CEXD(s0, s1) FR3D_CEXD(s2, s3) FR3D_CEXD(s0, s2) FR3D_CEXD(s1, s3) FR3D_CEXD(s1, s2)
-#undef FR3D_CEXD
-        m = r == 0 ? s0 : (r == 1 ? s1 : (r == 2 ? s2 : s3));
-    } else {
-        // many values inside one fp32 interval (flat regions): the r-th smallest of them by counting, O(ties * 125)
-        m = (double)v;
-        for (int a = 0; a < 5; a++)
-            for (int b = 0; b < 5; b++)
-                for (int c = 0; c < 5; c++) {
-                    const double cand = src[zo[a] + yo[b] + xo[c]];
-                    if ((float)cand != v) continue;
-                    int less = 0, eq = 0;
-                    for (int a2 = 0; a2 < 5; a2++)
-                        for (int b2 = 0; b2 < 5; b2++)
-                            for (int c2 = 0; c2 < 5; c2++) {
-                                const double o = src[zo[a2] + yo[b2] + xo[c2]];
-                                if ((float)o != v) continue;
-                                less += o < cand ? 1 : 0;
-                                eq += o == cand ? 1 : 0;
-                            }
-                    if (less <= r && r < less + eq) m = cand;
-                }
+        __syncthreads();
     }
-    float *__restrict__ out = dst.p[blockIdx.y];
-    out[t] = dst.acc ? (float)((double)out[t] + m) : (float)m;
 }
 
 // level flow += increments without a median (levels of at most 5 voxels per axis): the same single rounding
@@ -593,7 +624,15 @@ void launch_median5_fields_f64(hipStream_t st, const double *in, long long fstri
     hipLaunchKernelGGL(k_median5_flat<double>, dim3(cdiv((long long)npairs, MF_T), 3), dim3(MF_T), 0, st, in, fstride, Z, Y, X,
                        npairs, tmp);
     FR3D_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_median5_refine, dim3(cdiv((long long)Z * Y * X, 256), 3), dim3(256), 0, st, in, v32, fstride, Z, Y, X, d);
+    const int nzb = cdiv(Z, MR_ZB);
+    FR3D_CHECK(cdiv(Y, MR_TY) <= 65535 && 3 * nzb <= 65535, "exact median tail: axis too long");
+    int dbg = 0;
+#ifdef FR3D_EXPERIMENTS
+    static const char *env = getenv("FR3D_MEDIAN_DBG");  // 1: skip the several-ties path (timing experiment)
+    dbg = env ? atoi(env) : 0;
+#endif
+    hipLaunchKernelGGL(k_median5_refine, dim3(cdiv(X, MR_TX), cdiv(Y, MR_TY), 3 * nzb), dim3(MR_TX, MR_TY), 0, st, in, v32, fstride, Z, Y, X,
+                       nzb, d, dbg);
     FR3D_LAUNCH_CHECK();
 }
 

@@ -148,7 +148,7 @@ def test_fullsize_flow_matches_oracle_sample(hip, case):
 
 @pytest.mark.parametrize("case,mode,lo,hi", [("cfg3", 1, 5e-5, 2e-4), ("cfg3", 2, 0.0, 1e-7), ("cfg2_recipe", 1, 3e-5, 1e-4),
                                               ("cfg2_recipe_s135", 1, 3e-5, 1.5e-4), ("cfg2_recipe", 2, 0.0, 1e-7),
-                                              ("cfg5", 3, 1e-4, 3.5e-4), ("cfg5_levels8", 3, 3e-5, 1.5e-4)])
+                                              ("cfg5", 3, 1e-4, 3.5e-4), ("cfg5_levels8", 3, 3e-5, 2e-4)])
 def test_other_storage_modes_are_measured_and_stated(hip, case, mode, lo, hi):
     """The storage modes AUTO does not pick, timed by bench.py beside the packed mode.  fp32 storage (solver_fp64=1, the
     mode SURVEY 8d's 76 B / update figure is defined on): 8.6e-5 at 256^3 on the recipe inputs (lattice mean; the central
