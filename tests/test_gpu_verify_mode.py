@@ -64,11 +64,11 @@ def test_verify_mode_with_initial_flow_and_voxel_weights(hip, ppow_oracle):
 
 
 def test_shipped_modes_differ_from_the_verified_path_by_rounding_only(hip):
-    """the fp64-storage mode against the verification mode on one case: 1.9e-6; fp32 storage 4e-5 (reformulated update, fp32 tail)"""
+    """the fp64-storage mode against the verification mode on one case: ~1e-7 (exact level tail; what is left is the fp32 rounding of the output); fp32 storage 4e-5"""
     from flowreg3d_amd.synthetic import make_pair
     fixed, moving, _ = make_pair((24, 40, 36), seed=11, channels=1)
     v = hip.get_displacement_verify(fixed, moving, **KW)
-    for mode, tol in ((2, 4e-6), (1, 8e-5)):
+    for mode, tol in ((2, 1e-6), (1, 8e-5)):
         f = hip.get_displacement(fixed, moving, solver_fp64=mode, **KW)
         d = np.linalg.norm(f - v, axis=-1)
         print(f"mode {mode} vs verification mode: mean {d.mean():.2e} max {d.max():.2e}")
