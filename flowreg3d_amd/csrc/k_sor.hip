@@ -151,7 +151,9 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
 #ifdef FR3D_SOR_SHFL
     constexpr bool lane_share = FR3D_SOR_SHFL != 0;
 #else
-    constexpr bool lane_share = std::is_same<S, double>::value;
+    // (one channel only: with more channels the psi branch's registers, not the loads, bound the wave -- 0.611 with
+    // lane sharing against 0.629 without at 256^3, two channels)
+    constexpr bool lane_share = std::is_same<S, double>::value && C == 1;
 #endif
     Rec<S, 3> qxm, qxp, qym, qyp, qzm, qzp;
     if constexpr (lane_share) {

@@ -18,12 +18,17 @@ n, nb = int(sys.argv[1]), int(sys.argv[2])
 lib = _lib.init(0)
 levels = {64: 2, 128: 3, 256: 4, 512: 5}[n]
 fixed, moving, _ = fast_pair((n, n, n))
-nv = n ** 3
+nc = int(os.environ.get("FR3D_PROBE_CHANNELS", "1"))
+if nc > 1:
+    import numpy as np
+    fixed = np.ascontiguousarray(np.stack([fixed] + [fixed[::-1] * 0.9 for _ in range(nc - 1)], -1))
+    moving = np.ascontiguousarray(np.stack([moving] + [moving[::-1] * 0.9 for _ in range(nc - 1)], -1))
+nv = n ** 3 * nc
 params = _lib.make_params(alpha=(0.25,) * 3, update_lag=5, iterations=100, min_level=0, levels=levels, eta=0.8,
-                          a_smooth=1.0, a_data=0.45, n_channels=1,
+                          a_smooth=1.0, a_data=0.45, n_channels=nc,
                           solver_fp64=int(os.environ.get("FR3D_PROBE_MODE", "1")))
 ref = lib.fr3d_dev_malloc(nv * 4); mov = lib.fr3d_dev_malloc(nv * 4 * nb)
-flows = lib.fr3d_dev_malloc(nv * 12 * nb); regs = lib.fr3d_dev_malloc(nv * 4 * nb)
+flows = lib.fr3d_dev_malloc(n ** 3 * 12 * nb); regs = lib.fr3d_dev_malloc(nv * 4 * nb)
 lib.fr3d_h2d(ref, fixed.ctypes.data, nv * 4)
 for b in range(nb):
     lib.fr3d_h2d(mov + b * nv * 4, moving.ctypes.data, nv * 4)
@@ -31,7 +36,7 @@ lib.fr3d_set_batch(nb)
 def run(prof):
     lib.fr3d_prof_enable(1 if prof else 0)
     if prof: lib.fr3d_prof_reset()
-    _lib.check(lib.fr3d_process_batch_dev(C.byref(params), mov, mov, ref, ref, None, None, nb, n, n, n, 1, 3, flows, regs,
+    _lib.check(lib.fr3d_process_batch_dev(C.byref(params), mov, mov, ref, ref, None, None, nb, n, n, n, nc, 3, flows, regs,
                                           C.cast(None, _lib.PROGRESS_FN), None))
     lib.fr3d_sync()
 t0 = time.time()
@@ -44,7 +49,7 @@ for _ in range(3):
          "tensor_ms": round(s["tensor"]["ms"] / nb, 2), "other_ms": round(s["other"]["ms"] / nb, 2), "wall_ms_per_vol": round(1e3 * wall / nb, 1)}
     if best is None or r["wall_ms_per_vol"] < best["wall_ms_per_vol"]: best = r
 import hashlib, numpy as np
-out = np.empty((n, n, n, 3), np.float32); lib.fr3d_d2h(out.ctypes.data, flows, nv * 12)
+out = np.empty((n, n, n, 3), np.float32); lib.fr3d_d2h(out.ctypes.data, flows, n ** 3 * 12)
 best["flow_sha"] = hashlib.sha256(out.tobytes()).hexdigest()[:12]
 st = C.c_double(0.0)
 lib.fr3d_stream_probe(1 << 28, 10, C.byref(st))
