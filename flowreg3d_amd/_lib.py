@@ -67,6 +67,11 @@ SIGNATURES = {
     "fr3d_get_displacement": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "fr3d_get_displacement_dev": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "fr3d_get_displacement_verify": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "fr3d_portable_pow": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "fr3d_spline_coefficients": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "fr3d_motion_tensor_f64": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _vp]),
+    "fr3d_level_solve_verify": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,
+                                          C.c_double, C.c_double, C.c_double, _vp]),
     "fr3d_warp": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_warp_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_process_batch": (C.c_int, [C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <map>
@@ -820,10 +821,29 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
         a.ax = (sc * p.alpha[0]) / (hx * hx);
         a.ay = (sc * p.alpha[1]) / (hy * hy);
         a.az = (sc * p.alpha[2]) / (hz * hz);
+#ifdef FR3D_EXPERIMENTS
+        auto dump = [&](const char *tag, int ch, const void *dev, size_t bytes) {
+            const char *dir = getenv("FR3D_VERIFY_DUMP");  // debugging aid: per-level intermediates as raw files
+            if (!dir) return;
+            std::vector<char> host(bytes);
+            FR3D_HIP(hipStreamSynchronize(e.st));
+            FR3D_HIP(hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost));
+            const std::string path = std::string(dir) + "/g_L" + std::to_string(L.idx) + "_" + tag + std::to_string(ch) + ".bin";
+            if (FILE *f = fopen(path.c_str(), "wb")) {
+                fwrite(host.data(), 1, bytes, f);
+                fclose(f);
+            }
+        };
+        dump("warpedf", 0, warped, nl * C * sizeof(float));
+        dump("uinitf", 0, uf, nl * 3 * sizeof(float));
+#endif
         launch_sor_verify(e.st, a, e.chain_sched(sk, p.iterations));
         // :517-529 in fp64: increments back to the natural order, 5^3 median, u = u + du
         double *dn = e.f64("vf_dnat", nl * 3);
         launch_unskew_unpack<double, double>(e.st, Drec, dn, (long long)nl, 3, sk);
+#ifdef FR3D_EXPERIMENTS
+        dump("res", 0, dn, nl * 3 * sizeof(double));
+#endif
 #ifdef FR3D_EXPERIMENTS
         // numerics experiment (which part of the shipped modes' difference is the fp32 level tail?): FR3D_VERIFY_TAIL32=1
         // rounds the increments to fp32 before the median and keeps the level flow in fp32, like the shipped modes
@@ -852,6 +872,9 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
             }
 #endif
         }
+#ifdef FR3D_EXPERIMENTS
+        for (int d = 0; d < 3; d++) dump("u", d, ud[d], nl * sizeof(double));
+#endif
         pz = lz; py = ly; px = lx;
     }
     // :530-541
@@ -1477,6 +1500,107 @@ int fr3d_get_displacement_verify(const fr3d_params *p, const float *fixed, const
     e.prof = prof;
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(flow_out, dout, nv * 3 * 8, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_spline_coefficients(const float *vol, int Z, int Y, int X, double *coef_out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(vol && coef_out && Z > 0 && Y > 0 && X > 0, "bad arguments");
+    FR3D_CHECK(prefilter_compact_ok(Z, Y, X), "spline coefficient hook: every axis must be at least 41 voxels long");
+    const size_t n = (size_t)Z * Y * X, np = (size_t)(Z + 4) * (Y + 4) * (X + 4);
+    Staged s;
+    const float *dv = (const float *)s.up(vol, n * 4);
+    double *coef = (double *)s.alloc(np * 8);
+    double *tmp = (double *)s.alloc((size_t)(Z + 4) * (Y + 4) * X * 8);
+    launch_prefilter3_compact<float>(g_eng.st, dv, 1, 0, Z, Y, X, coef, tmp);
+    FR3D_HIP(hipStreamSynchronize(g_eng.st));
+    FR3D_HIP(hipMemcpy(coef_out, coef, np * 8, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_motion_tensor_f64(const float *f1, const float *f2, int Z, int Y, int X, double hz, double hy, double hx,
+                           double *J_out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(f1 && f2 && J_out && Z > 0 && Y > 0 && X > 0, "bad arguments");
+    const size_t n = (size_t)Z * Y * X;
+    Staged s;
+    const float *d1 = (const float *)s.up(f1, n * 4);
+    const float *d2 = (const float *)s.up(f2, n * 4);
+    double *dj = (double *)s.alloc(n * 10 * 8);
+    double *Jo[10];
+    for (int q = 0; q < 10; q++) Jo[q] = dj + (size_t)q * n;
+    launch_motion_tensor<double, double>(g_eng.st, d1, d2, Z, Y, X, hz, hy, hx, Jo, (double *)nullptr, 0, nullptr);
+    FR3D_HIP(hipStreamSynchronize(g_eng.st));
+    FR3D_HIP(hipMemcpy(J_out, dj, n * 10 * 8, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_level_solve_verify(const double *J, const float *weight, const float *uvw, int Z, int Y, int X, int C,
+                            const double *alpha3, int iterations, int update_lag, const double *a_data, double hx,
+                            double hy, double hz, double *duvw_out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(J && weight && uvw && alpha3 && a_data && duvw_out, "NULL pointer");
+    FR3D_CHECK(Z > 0 && Y > 0 && X > 0 && C >= 1 && C <= FR3D_MAX_CHANNELS, "bad solver shape");
+    FR3D_CHECK(iterations >= 0 && update_lag >= 1, "iterations >= 0 and update_lag >= 1 required");
+    Engine &e = g_eng;
+    const size_t n = (size_t)Z * Y * X;
+    const Skew sk = e.compact_skew(Z, Y, X);
+    const size_t ns = (size_t)sk.total;
+    Staged s;
+    const double *dJ = (const double *)s.up(J, n * 10 * C * 8);   // (C, 10, Z, Y, X)
+    const float *dW = (const float *)s.up(weight, n * C * 4);      // (C, Z, Y, X)
+    const float *dU = (const float *)s.up(uvw, n * 3 * 4);         // (3, Z, Y, X)
+    double *Jrec = (double *)s.alloc(ns * 10 * C * 8);
+    float *wrec = (float *)s.alloc(ns * C * 4);
+    double *psi = (double *)s.alloc(ns * C * 8);
+    double *Urec = (double *)s.alloc(ns * 3 * 8);
+    double *Drec = (double *)s.alloc(ns * 3 * 8);
+    double *dn = (double *)s.alloc(n * 3 * 8);
+    VerifyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.sk = sk;
+    a.C = C;
+    a.update_lag = update_lag;
+    for (int c = 0; c < C; c++) {
+        launch_skew_pack<double, double>(e.st, dJ + (size_t)c * 10 * n, (long long)n, Jrec + (size_t)c * 10 * ns, 10, sk);
+        launch_skew_pack<float, float>(e.st, dW + (size_t)c * n, 0, wrec + (size_t)c * ns, 1, sk);
+        a.J[c] = Jrec + (size_t)c * 10 * ns;
+        a.w[c] = wrec + (size_t)c * ns;
+        a.psi[c] = psi + (size_t)c * ns;
+        a.a_data[c] = a_data[c];
+    }
+    launch_skew_pack<float, double>(e.st, dU, (long long)n, Urec, 3, sk);
+    FR3D_HIP(hipMemsetAsync(Drec, 0, ns * 3 * 8, e.st));
+    a.U = Urec;
+    a.D = Drec;
+    a.ax = alpha3[0] / (hx * hx);
+    a.ay = alpha3[1] / (hy * hy);
+    a.az = alpha3[2] / (hz * hz);
+    launch_sor_verify(e.st, a, e.chain_sched(sk, iterations));
+    launch_unskew_unpack<double, double>(e.st, Drec, dn, (long long)n, 3, sk);
+    FR3D_HIP(hipStreamSynchronize(e.st));
+    FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 8, hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
+
+int fr3d_portable_pow(const double *x, const double *y, size_t n, double *out)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(x && y && out, "NULL pointer");
+    Staged s;
+    const double *dx = (const double *)s.up(x, n * 8);
+    const double *dy = (const double *)s.up(y, n * 8);
+    double *dout = (double *)s.alloc(n * 8);
+    launch_ppow(g_eng.st, dx, dy, (long long)n, dout);
+    FR3D_HIP(hipStreamSynchronize(g_eng.st));
+    FR3D_HIP(hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost));
     FR3D_CATCH
 }
 

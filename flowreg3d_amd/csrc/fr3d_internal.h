@@ -217,6 +217,7 @@ void launch_median5_f64(hipStream_t st, const double *in, int Z, int Y, int X, d
 template <typename TS, typename TD>
 void launch_cast(hipStream_t st, const TS *src, long long n, TD *dst);
 void launch_axpy_f64(hipStream_t st, double *y, const double *x, long long n);
+void launch_ppow(hipStream_t st, const double *x, const double *y, long long n, double *out);
 void launch_pack3_f64(hipStream_t st, const double *a, const double *b, const double *c, long long n, double *out);
 
 // ---- a_smooth != 1 solver path (k_sor_smooth.hip) ------------------------------------------------

@@ -237,6 +237,18 @@ void launch_axpy_f64(hipStream_t st, double *y, const double *x, long long n)
     FR3D_LAUNCH_CHECK();
 }
 
+// test hook: the portable pow on the device (tests compare it bit for bit with the same source compiled by gcc)
+__global__ void k_ppow(const double *__restrict__ x, const double *__restrict__ y, long long n, double *__restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = fr3d_ppow(x[t], y[t]);
+}
+void launch_ppow(hipStream_t st, const double *x, const double *y, long long n, double *out)
+{
+    hipLaunchKernelGGL(k_ppow, dim3(cdiv(n, 256)), dim3(256), 0, st, x, y, n, out);
+    FR3D_LAUNCH_CHECK();
+}
+
 // (Z,Y,X,3) interleaved fp64 flow from three planar arrays
 __global__ void k_pack3_f64(const double *__restrict__ a, const double *__restrict__ b, const double *__restrict__ c, long long n,
                             double *__restrict__ out)

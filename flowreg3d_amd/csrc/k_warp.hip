@@ -14,7 +14,11 @@
 
 namespace fr3d {
 
-#define SPL_POLE (-0.26794919243112270647)  // sqrt(3) - 2
+// sqrt(3.0) - 2.0 AS SciPy EVALUATES IT (ni_splines.c get_filter_poles: double arithmetic on the rounded square root):
+// two ulp from the correctly rounded value of the real number, -0.26794919243112270647 = -0x1.126145e9ecd56p-2, which the
+// engine used until round 3 -- invisible in fp32 outputs except on one voxel in a few million, where the fp64 tap sum
+// sits on a rounding boundary (found through the verification mode at 128x160x192)
+#define SPL_POLE (-0x1.126145e9ecd58p-2)
 
 __device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 

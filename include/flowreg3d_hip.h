@@ -105,6 +105,27 @@ int fr3d_get_displacement_dev(const fr3d_params *p, const float *fixed, const fl
 int fr3d_get_displacement_verify(const fr3d_params *p, const float *fixed, const float *moving, int Z, int Y, int X,
                                  int C, const float *uvw_init, const float *weight, double *flow_out);
 
+/* Test hook: the cubic B-spline coefficients of a float32 volume as the gather reads them (pad-free prefilter,
+ * coefficients -2 .. N+1 per axis): coef_out (Z+4,Y+4,X+4) float64 = SciPy's spline_filter of the volume padded by 12
+ * replicated voxels, cropped to that range.  Every axis at least 41 voxels. */
+int fr3d_spline_coefficients(const float *vol, int Z, int Y, int X, double *coef_out);
+
+/* Test hook: the gradient-constancy motion tensor in float64 as the verification mode forms it (no rounding to the
+ * solver's storage): J_out (10,Z,Y,X) float64, order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34. */
+int fr3d_motion_tensor_f64(const float *f1, const float *f2, int Z, int Y, int X, double hz, double hy, double hx,
+                           double *J_out);
+
+/* Test hook: the verification mode's sweep alone (k_verify.hip) -- level_solver in the reference's arithmetic.
+ * J: (C,10,Z,Y,X) float64 tensor entries in the order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 (interior, no ghost
+ * ring); weight (C,Z,Y,X) and uvw (3,Z,Y,X) float32; duvw_out (3,Z,Y,X) float64.  a_smooth == 1. */
+int fr3d_level_solve_verify(const double *J, const float *weight, const float *uvw, int Z, int Y, int X, int C,
+                            const double *alpha3, int iterations, int update_lag, const double *a_data, double hx,
+                            double hy, double hz, double *duvw_out);
+
+/* Test hook: the verification mode's portable pow (flowreg3d_amd/csrc/portable_pow.h) evaluated on the device for n
+ * host values -- tests compare it bit for bit with the same source compiled for the host. */
+int fr3d_portable_pow(const double *x, const double *y, size_t n, double *out);
+
 /* imregister_wrapper (core/optical_flow_3d.py:22-74): backward warp of `vol` by `flow`,
  * out-of-bounds voxels taken from `ref`.  order 3 = cubic B-spline with SciPy's prefilter,
  * order 1 = linear.  vol/ref (Z,Y,X,C) of vol_dtype; flow (Z,Y,X,3) of flow_dtype;

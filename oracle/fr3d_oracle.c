@@ -729,6 +729,20 @@ void fr3d_oracle_compute_flow_3d(const double *const J[10], const double *weight
     free(du); free(dv); free(dw); free(psi_s); free(psi);
 }
 
+/* debugging aid of the tests: FR3D_ORACLE_DUMP=<dir> writes per-level intermediate arrays as raw float64 */
+#include <stdio.h>
+static void dbg_dump(const char *tag, int level, int ch, const double *a, size_t n)
+{
+    const char *dir = getenv("FR3D_ORACLE_DUMP");
+    if (!dir) return;
+    char path[512];
+    snprintf(path, sizeof(path), "%s/o_L%d_%s%d.bin", dir, level, tag, ch);
+    FILE *f = fopen(path, "wb");
+    if (!f) return;
+    fwrite(a, sizeof(double), n, f);
+    fclose(f);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* K8  exact 5x5x5 median, mirror boundary       scipy.ndimage.median_filter (rank 62 of 125)  */
 /* ------------------------------------------------------------------------------------------ */
@@ -959,6 +973,8 @@ int fr3d_oracle_get_displacement(const double *fixed, const double *moving, int 
         free(u); free(v); free(w);
         u = un; v = vn; w = wn;
         free(ui); free(vi); free(wi);
+        dbg_dump("warped", i, 0, warped, nl * C);
+        dbg_dump("uinit", i, 0, u, npad);
 
         /* :440-473  motion tensor per channel into (P,M,N,C) */
         double *J[10], *Jc[10];
@@ -1001,6 +1017,7 @@ int fr3d_oracle_get_displacement(const double *fixed, const double *moving, int 
         fr3d_oracle_compute_flow_3d((const double *const *)J, wl, u, v, w, P, M, N, C, at[0], at[1],
                                     at[2], iterations, update_lag, a_data, a_smooth, hx, hy, hz,
                                     res);
+        dbg_dump("res", i, 0, res, npad * 3);
         /* :517-529 */
         double *dint = (double *)xmalloc(sizeof(double) * nl);
         double *dmed = (double *)xmalloc(sizeof(double) * nl);
@@ -1021,6 +1038,7 @@ int fr3d_oracle_get_displacement(const double *fixed, const double *moving, int 
                                 dmed[IDX3(a, b, e, ly, lx)];
             }
             for (size_t q = 0; q < npad; q++) uvwp[d][q] = uvwp[d][q] + res[q * 3 + d];
+            dbg_dump("u", i, d, uvwp[d], npad);
         }
         free(dint); free(dmed); free(res); free(wl);
         for (int a = 0; a < 10; a++) free(J[a]);

@@ -92,3 +92,28 @@ def test_fullsize_verify_mode_is_bit_identical_to_the_ppow_oracle_sample(hip, ca
     assert g["lattice"].dtype == np.float64
     _same(flow[::st, ::st, ::st], g["lattice"], f"{case} lattice")
     _same(flow[z0:z0 + bl, y0:y0 + bl, x0:x0 + bl], g["block"], f"{case} block")
+
+
+def test_portable_pow_gives_the_same_bits_on_device_and_host(hip):
+    """the premise of the verification mode: portable_pow.h compiled by hipcc for gfx950 and by gcc for the host agree
+    bit for bit -- 20 million arguments over the ranges the psi nonlinearities feed it"""
+    import ctypes as C
+    import sys
+    from flowreg3d_amd import _lib
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_portable_pow import _build
+    host = _build()
+    lib = _lib.init(0)
+    rng = np.random.default_rng(5)
+    n = 5_000_000
+    dp = C.POINTER(C.c_double)
+    for k, (x, y) in enumerate([(10.0 ** rng.uniform(-6, 8, n), rng.uniform(-1.0, 0.0, n)),
+                                (1e-6 + rng.random(n) * 1e-4, np.full(n, -0.55)),
+                                (1e-6 + 10.0 ** rng.uniform(-9, 3, n), np.full(n, -0.55)),
+                                (1.0 + rng.normal(0, 0.3, n) ** 2, rng.choice([-0.55, -0.5, -0.9, -0.1], n))]):
+        x = np.ascontiguousarray(x); y = np.ascontiguousarray(y)
+        a = np.empty(n); b = np.empty(n)
+        host.ppow_many(x.ctypes.data_as(dp), y.ctypes.data_as(dp), n, a.ctypes.data_as(dp))
+        _lib.check(lib.fr3d_portable_pow(_lib.ptr(x), _lib.ptr(y), n, _lib.ptr(b)))
+        bad = np.flatnonzero(a != b)
+        assert bad.size == 0, (k, bad.size, x[bad[:3]], y[bad[:3]], a[bad[:3]], b[bad[:3]])
