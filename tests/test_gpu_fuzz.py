@@ -27,6 +27,25 @@ def test_random_shapes_and_parameters_in_the_default_solver_mode(hip, oracle):
     assert bad == 0 and worst < 2e-4, (bad, worst)
 
 
+def test_random_shapes_and_parameters_in_packed_storage(hip, oracle):
+    """packed 42-bit solver storage forced on the same generator (tiny volumes, 1..6 channels, a_smooth 1 and 0.5 --
+    the latter falls back to fp64 storage)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_vs_oracle
+    bad, worst = fuzz_vs_oracle.run(n_cases=30, seed=31, verbose=False, mode=3)
+    assert bad == 0 and worst < 2e-4, (bad, worst)
+
+
+def test_verification_mode_is_bit_identical_on_random_shapes_and_parameters(hip, oracle):
+    """the verification mode against the oracle's ppow build on the random generator (axes of length 1..70, 1..6
+    channels, random pyramid / solver parameters, initial flows, weights): np.array_equal on every case, and the
+    inputs the reference rejects are rejected"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_vs_oracle
+    bad, worst = fuzz_vs_oracle.run(n_cases=40, seed=47, verbose=False, mode="verify")
+    assert bad == 0, (bad, worst)
+
+
 @pytest.mark.parametrize("C", [4, 5, 8])
 def test_many_channels_match_the_oracle(hip, oracle, C):
     """C = 4 (last unrolled instantiation), 5 and 8 = FR3D_MAX_CHANNELS (channel loop bound at run time):

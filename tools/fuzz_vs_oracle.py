@@ -3,7 +3,7 @@ parity solver mode (solver_fp64=2, fp64 solver storage; bound: mean EPE < 1e-4 *
 library's DEFAULT mode (solver_fp64=None -> FR3D_SOLVER_AUTO: fp32 solver storage with fp64 update arithmetic
 for one channel, fp64 storage for several; bound 2e-4 * scale on these small, partly ill-conditioned random
 cases -- the north-star 1e-4 is asserted on the BASELINE configurations, tests/test_gpu_fullsize_parity.py).
-usage (GPU box): python tools/fuzz_vs_oracle.py [n_cases] [seed] [auto|2]"""
+usage (GPU box): python tools/fuzz_vs_oracle.py [n_cases] [seed] [auto|2|3|verify]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,8 +16,13 @@ from scipy.ndimage import gaussian_filter
 
 def run(n_cases=40, seed=0, verbose=True, mode=2):
     """-> (number of failing cases, worst mean EPE relative to max(1, |flow|max)); mode 2 = fp64 solver storage,
-    None = the library's automatic choice"""
-    tol = 1e-4 if mode == 2 else 2e-4
+    3 = packed 42-bit storage, None = the library's automatic choice, "verify" = the verification mode against the
+    oracle's `ppow` build, where the bound is BIT-IDENTITY of the float64 flow (a_smooth is forced to 1)"""
+    verify = mode == "verify"
+    tol = 0.0 if verify else (1e-4 if mode == 2 else 2e-4)
+    if verify:
+        oracle.build()
+        oracle.use_build("ppow")
     say = print if verbose else (lambda *a, **k: None)
     rng = np.random.default_rng(seed)
     _lib.init()
@@ -37,6 +42,8 @@ def run(n_cases=40, seed=0, verbose=True, mode=2):
                   iterations=int(rng.integers(0, 25)), min_level=int(rng.integers(0, 4)), levels=int(rng.integers(1, 12)),
                   eta=float(rng.choice([0.5, 0.75, 0.8, 0.9])), a_smooth=float(rng.choice([1.0, 1.0, 0.5])),
                   a_data=float(rng.choice([0.45, 1.0, 0.3])))
+        if verify:
+            kw["a_smooth"] = 1.0
         if C > 1 and rng.random() < 0.5:
             kw["weight"] = rng.uniform(0.2, 1.0, C)
         uvw = None
@@ -48,16 +55,22 @@ def run(n_cases=40, seed=0, verbose=True, mode=2):
             except ValueError:
                 # input the reference itself rejects (e.g. a pyramid level rounded to size 0): the GPU path must refuse too
                 try:
-                    fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, **kw)
+                    if verify:
+                        fr.get_displacement_verify(fixed, moving, uvw=None if uvw is None else uvw.copy(), **kw)
+                    else:
+                        fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, **kw)
                     bad += 1
                     say("BAD case %2d shape %s: oracle rejects, GPU path accepted" % (case, shape), flush=True)
                 except (ValueError, RuntimeError):
                     say("ok  case %2d shape %s C=%d: rejected by both" % (case, shape, C), flush=True)
                 continue
-            got = fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, **kw)
+            if verify:
+                got = fr.get_displacement_verify(fixed, moving, uvw=None if uvw is None else uvw.copy(), **kw)
+            else:
+                got = fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, **kw)
             d = np.linalg.norm(got - want, axis=-1)
             scale = max(1.0, float(np.abs(want).max()))
-            ok = np.isfinite(got).all() and d.mean() < tol * scale
+            ok = np.isfinite(got).all() and (np.array_equal(got, want) if verify else d.mean() < tol * scale)
             worst = max(worst, d.mean() / scale)
             if not ok:
                 bad += 1
@@ -67,12 +80,14 @@ def run(n_cases=40, seed=0, verbose=True, mode=2):
         except Exception as e:  # noqa
             bad += 1
             say("EXC case %d shape %s C=%d %s: %r" % (case, shape, C, kw, e), flush=True)
+    if verify:
+        oracle.use_build("")
     return bad, worst
 
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     sd = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    md = None if (len(sys.argv) > 3 and sys.argv[3] == "auto") else 2
+    md = {"auto": None, "verify": "verify", "3": 3}.get(sys.argv[3], 2) if len(sys.argv) > 3 else 2
     bad, worst = run(n, sd, mode=md)
     print("cases %d bad %d worst scaled mean EPE %.2e" % (n, bad, worst))
