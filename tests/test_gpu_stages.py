@@ -291,3 +291,23 @@ def test_resampler_options_match_the_reference(hip):
                                ("i16_mixed", "i16", (18, 30, 13), dict(per_axis=True))):
         got = hip.imresize_fused_gauss_cubic3D(g[src], size, **kw)
         assert got.dtype == g[key].dtype and np.array_equal(got, g[key]), key
+
+
+def test_level_solver_accepts_the_engines_own_fp32_grade_tensor(hip):
+    """`level_solver(*get_motion_tensor_gc(...))` -- the tensor comes back as float64 arrays holding the
+    engine's float32 storage, whose smallest eigenvalue sits at ~1e-7 of the trace; the rank-3 guard of
+    core.tensor_factors scales its threshold to the input's precision instead of refusing it."""
+    from flowreg3d_amd.synthetic import make_pair
+    fixed, moving, _ = make_pair((12, 20, 18), seed=6)
+    J = hip.get_motion_tensor_gc(fixed, moving, 1.0, 1.0, 1.0)
+    P, M, N = J[0].shape
+    wt = np.zeros((P, M, N))
+    wt[1:-1, 1:-1, 1:-1] = 1.0
+    z = np.zeros((P, M, N))
+    du, dv, dw = hip.level_solver(*J, wt, z, z, z, (0.25, 0.25, 0.25), 10, 5, False, 0.45, 1.0, 1.0, 1.0, 1.0)
+    assert du.shape == (P, M, N) and np.isfinite(du).all() and np.abs(du).max() > 0
+    # a tensor that is genuinely not rank 3 is still refused
+    bad = [j.copy() for j in J]
+    bad[0] = bad[0] + 0.1 * (np.abs(bad[0]).max() + 1.0)
+    with pytest.raises(ValueError):
+        hip.level_solver(*bad, wt, z, z, z, (0.25, 0.25, 0.25), 3, 5, False, 0.45, 1.0, 1.0, 1.0, 1.0)
