@@ -628,6 +628,9 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
             sa.iterations = p.iterations;
             sa.update_lag = p.update_lag;
             sa.S_planes = sk.S;
+#ifdef FR3D_EXPERIMENTS
+            if (const char *v = std::getenv("FR3D_SM_DBG")) sa.dbg = std::atoi(v);
+#endif
             {
                 float *stage = e.f32("d_nat", nl * 3);  // the increments' scratch is free until the solver has run
                 for (int b = 0; b < nb; b++) {

@@ -247,6 +247,7 @@ struct SmoothArgs {
     double ax, ay, az;
     double a_data[FR3D_MAX_CHANNELS];
     int C, iterations, update_lag, S_planes, nvol;
+    int dbg;                 // experiment build only (FR3D_SM_DBG): kinds of workgroups left out of a step, for timing
 };
 template <typename S>
 inline void smooth_set_spacing(SmoothView<S> &v, double hx, double hy, double hz)

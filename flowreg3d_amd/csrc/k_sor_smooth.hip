@@ -210,6 +210,9 @@ __device__ __forceinline__ void psi_voxel(const SmoothArgs<S> &a, const SmoothPo
             g += dz * dz;
         }
         if (g < 0.0) g = 0.0;
+#ifdef FR3D_EXPERIMENTS
+        if (a.dbg & 16) ps = g; else  // no pow
+#endif
         if (sizeof(S) == 4) ps = v.a_smooth * (double)powf((float)(g + 1e-5), (float)(v.a_smooth - 1.0));
         else ps = v.a_smooth * pow(g + 1e-5, v.a_smooth - 1.0);
     } else {
@@ -356,21 +359,30 @@ k_smooth_step(const SmoothArgs<S> a, StepPart P, StepPart W, int cb, const int *
 {
     int b = blockIdx.x;
     SmoothPos p;
+#ifdef FR3D_EXPERIMENTS  // FR3D_SM_DBG: 1 / 2 = no P-stage / sweep tiles, 4 / 8 = no P-stage / sweep surface workgroups
+#define SM_SKIP(bit) if (a.dbg & (bit)) return;
+#else
+#define SM_SKIP(bit)
+#endif
     if (b < P.ntiles) {
+        SM_SKIP(1)
         if (locate_tile(a, b, P, p)) psi_voxel<S, true>(a, p);
         return;
     }
     b -= P.ntiles;
     if (b < W.ntiles) {
+        SM_SKIP(2)
         if (locate_tile(a, b, W, p)) sweep_voxel<S, C, true>(a, p);
         return;
     }
     b -= W.ntiles;
     if (b < P.nt * cb) {
+        SM_SKIP(4)
         if (locate_surface(a, b, cb, P, meta, kj, p)) psi_voxel<S, false>(a, p);
         return;
     }
     b -= P.nt * cb;
+    SM_SKIP(8)
     if (locate_surface(a, b, cb, W, meta, kj, p)) sweep_voxel<S, C, false>(a, p);
 }
 

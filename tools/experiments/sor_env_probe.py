@@ -27,7 +27,7 @@ def main():
     fixed, moving, _ = fast_pair((n, n, n))
     nv = n ** 3
     params = _lib.make_params(alpha=(0.25,) * 3, update_lag=5, iterations=100, min_level=0, levels=levels, eta=0.8,
-                              a_smooth=1.0, a_data=0.45, n_channels=1,
+                              a_smooth=float(os.environ.get("FR3D_PROBE_ASMOOTH", "1.0")), a_data=0.45, n_channels=1,
                               solver_fp64=int(os.environ.get("FR3D_PROBE_MODE", "1")))
     ref = lib.fr3d_dev_malloc(nv * 4)
     mov = lib.fr3d_dev_malloc(nv * 4 * nb)
