@@ -43,7 +43,14 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
     const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X;
     // blockIdx.x enumerates the tiles of all groups of this launch (schedule built on the host)
     const int vol = blockIdx.y;
+#ifdef FR3D_SOR_XCD
+    // variant build: workgroups are dealt round-robin over the 8 XCDs, so give the ids that share an XCD (equal id % 8)
+    // one contiguous eighth of the tile list (neighbouring row blocks of one plane then meet in one L2)
+    const int q8 = gridDim.x >> 3, r8 = gridDim.x & 7, x8 = blockIdx.x & 7;
+    const int b = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (int)(blockIdx.x >> 3);
+#else
     const int b = blockIdx.x;
+#endif
     // find the group: the table gives the entry of the first tile of this tile group, a short
     // forward scan does the rest (a bisection costs ~7 dependent scalar loads before the first
     // vector load can be issued)
