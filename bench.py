@@ -16,7 +16,7 @@ core and all cores).  At N = 1 the default run adds two legs to the same line, a
 the headline workload: `host_path` (NumPy arrays in, NumPy arrays out through fr3d_process_batch: the
 PCIe-inclusive rate of the drop-in entry, never `value`) and `cfg3` (the 512^3 six-level configuration,
 4 timed steps at lock-step batch 4, with its own `roofline`) and `a_smooth_0.5` (the psi_smooth solver path on
-the cfg2 geometry); `--no-extras` skips them.
+the cfg2 geometry) and `two_lanes` (the headline workload with fr3d_set_lanes(2)); `--no-extras` skips them.
 """
 import argparse
 import ctypes as C
@@ -513,6 +513,20 @@ def main():
                                    "solver": SOLVER_NAMES[sm["mode"]], "parity_mean_epe_vs_cpu_path": parity_record("cfg2_asmooth05", sm["mode"], False)[0],
                                    "parity_source": parity_record("cfg2_asmooth05", sm["mode"], False)[1],
                                    "roofline": sm["roofline"], "kernel_ms_per_step": sm["kernel_ms_per_step"]}
+            # (4) two engine lanes (fr3d_set_lanes(2): lock-step batches of 4 alternate between two streams, so that the
+            # stages beside the sweep run under the other lane's sweep) on the headline workload -- the headline itself
+            # stays on one lane: per-kernel times of overlapping lanes are not exclusive kernel times
+            _lib.shutdown()
+            lib = _lib.init(dev_index)
+            lib.fr3d_set_lanes(2)
+            try:
+                tl = measure(lib, _lib, "cfg2", 8, 1, 0, 8.0, args.solver_fp64, 0, 1, None, dev_index, fast_inputs=False)
+            finally:
+                lib.fr3d_set_lanes(1)
+            out["two_lanes"] = {"workload": "cfg2, fr3d_set_lanes(2): two lock-step batches of 4 in flight on two HIP streams",
+                                "value": 8 / tl["elapsed"], "unit": "volumes/sec", "steps": 8, "warmup": 1,
+                                "ms_per_step": 1e3 * tl["elapsed"] / 8, "vs_one_lane": (8 / tl["elapsed"]) / out["value"],
+                                "results": "bit-identical to one lane (tests/test_gpu_executor.py)"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -63,6 +63,7 @@ SIGNATURES = {
     "fr3d_version": (C.c_char_p, []),
     "fr3d_device_info": (C.c_char_p, []),
     "fr3d_set_batch": (C.c_int, [C.c_int]),
+    "fr3d_set_lanes": (C.c_int, [C.c_int]),
     "fr3d_last_solver_mode": (C.c_int, []),
     "fr3d_get_displacement": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "fr3d_get_displacement_dev": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),

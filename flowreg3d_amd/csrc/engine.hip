@@ -316,6 +316,13 @@ struct Engine {
 };
 
 static Engine g_eng;
+// Second lane (fr3d_set_lanes(2)): an engine of its own -- stream, workspace, tables, schedules -- on the same device.
+// fr3d_process_batch* then deals the lock-step batches of a series alternately to the two lanes, so that the
+// compute-bound stages of one lane (median, warp, motion tensor, the coarse levels' short launches) run under the
+// other lane's sweep.  Everything else (single-volume entries, preprocessing, statistics) runs on lane 0.
+static Engine g_eng2;
+static int g_lanes = 1;
+static Engine *g_cur = &g_eng;  // the lane the stage wrappers below enqueue on (calls are serialised by g_mu)
 static std::recursive_mutex g_mu;
 static thread_local std::string g_err;
 
@@ -977,8 +984,9 @@ static double solver_budget(const std::vector<Level> &lv, int C)
     // 85 % of the device.  Memory the caller holds (a resident series, torch tensors) is respected.
     // (the host-staging windows "stg*" of fr3d_process_batch_raw stay in use during the call: not reusable)
     size_t held = 0;
-    for (const auto &kv : g_eng.bufs)
-        if (kv.first.compare(0, 3, "stg") != 0) held += kv.second.cap;
+    for (const Engine *en : {&g_eng, &g_eng2})
+        for (const auto &kv : en->bufs)
+            if (kv.first.compare(0, 3, "stg") != 0) held += kv.second.cap;
     const double avail = (double)free_b + (double)held - scratch - 2.0 * 1073741824.0;
     return std::min(0.85 * (double)total_b, avail);
 }
@@ -1043,7 +1051,7 @@ template <typename TV, typename TF, typename TR = TV, typename TO = float>
 static void warp_dev_t(const TV *vol, const TF *flow, const TR *ref, int Z, int Y, int X, int C, int order,
                        TO *out)
 {
-    Engine &e = g_eng;
+    Engine &e = *g_cur;
     for (int c = 0; c < C; c++) {
         if (order == 3) {
             warp_cubic_chan<TV, TF, TR, TO>(e, vol, C, c, flow + 0, flow + 1, flow + 2, 3, 1.0, 1.0, 1.0, ref, Z, Y,
@@ -1140,30 +1148,67 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
         g_storage_bytes = m == 2 ? 8.0 : (m == 3 ? 16.0 / 3.0 : 4.0);
     }
     g_fast_path = p->a_smooth == 1.0;
-    const int B = T > 0 ? pick_batch(T, lv, C) : 1;
+    int B = T > 0 ? pick_batch(T, lv, C) : 1;
+    // two lanes: each takes lock-step batches of half the size (same workspace in total), alternately
+    const bool two = g_lanes == 2 && g_eng2.inited && T >= 2 && B >= 2;
+    if (two) B = cdiv(B, 2);
+    const int reserve = g_batch_hint > 0 ? std::max(1, pick_batch(g_batch_hint, lv, C) / (two ? 2 : 1)) : B;
+    hipEvent_t ev_start = nullptr;
+    std::vector<std::pair<hipEvent_t, int>> done;  // two lanes: completion event and volume count of every batch
+    if (two) {
+        // lane 1 starts after everything enqueued on lane 0 so far: the caller's inputs and the reference pyramid
+        FR3D_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+        FR3D_HIP(hipEventRecord(ev_start, e.st));
+        FR3D_HIP(hipStreamWaitEvent(g_eng2.st, ev_start, 0));
+    }
     // T volumes in ceil(T/B) lock-step batches of (nearly) equal size: 10 volumes at B = 4 run as
     // 4+3+3, not 4+4+2 (the shared launches amortise best over evenly filled batches)
     int chunks_left = T > 0 ? cdiv(T, B) : 0;
-    for (int t0 = 0, nb = 0; t0 < T; t0 += nb, chunks_left--) {
-        nb = cdiv(T - t0, chunks_left);
-        std::vector<const float *> mov(nb);
-        std::vector<float *> fl(nb);
-        for (int b = 0; b < nb; b++) {
-            mov[b] = batch_proc + (size_t)(t0 + b) * nv * C;
-            fl[b] = flows_out + (size_t)(t0 + b) * nv * 3;
+    int chunk = 0;
+    try {
+        for (int t0 = 0, nb = 0; t0 < T; t0 += nb, chunks_left--, chunk++) {
+            nb = cdiv(T - t0, chunks_left);
+            Engine &lane = two && (chunk & 1) ? g_eng2 : e;
+            std::vector<const float *> mov(nb);
+            std::vector<float *> fl(nb);
+            for (int b = 0; b < nb; b++) {
+                mov[b] = batch_proc + (size_t)(t0 + b) * nv * C;
+                fl[b] = flows_out + (size_t)(t0 + b) * nv * 3;
+            }
+            get_displacement_core(lane, *p, lv, min_level, rp, nb, mov.data(), Z, Y, X, C, w_init, fl.data(), reserve);
+            g_cur = &lane;
+            for (int b = 0; b < nb; b++) {
+                const size_t o = (size_t)(t0 + b) * nv * C * esz;
+                warp_raw((const char *)batch_raw + o, raw_dtype, fl[b], ref_raw, ref_dtype, Z, Y, X, C, order,
+                         (char *)registered_out + o);
+            }
+            g_cur = &g_eng;
+            if (two) {
+                // nothing waits here: the host runs ahead and both lanes stay busy; progress is reported below
+                hipEvent_t ev;
+                FR3D_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                done.emplace_back(ev, nb);
+                FR3D_HIP(hipEventRecord(ev, lane.st));
+            } else if (progress) {
+                FR3D_HIP(hipStreamSynchronize(e.st));
+                for (int b = 0; b < nb; b++) progress(1, user);
+            }
         }
-        get_displacement_core(e, *p, lv, min_level, rp, nb, mov.data(), Z, Y, X, C, w_init, fl.data(),
-                              g_batch_hint > 0 ? pick_batch(g_batch_hint, lv, C) : B);
-        for (int b = 0; b < nb; b++) {
-            const size_t o = (size_t)(t0 + b) * nv * C * esz;
-            warp_raw((const char *)batch_raw + o, raw_dtype, fl[b], ref_raw, ref_dtype, Z, Y, X, C, order,
-                     (char *)registered_out + o);
+        for (auto &d : done) {
+            FR3D_HIP(hipEventSynchronize(d.first));
+            if (progress)
+                for (int b = 0; b < d.second; b++) progress(1, user);
         }
-        if (progress) {
-            FR3D_HIP(hipStreamSynchronize(e.st));
-            for (int b = 0; b < nb; b++) progress(1, user);
-        }
+    } catch (...) {
+        g_cur = &g_eng;
+        (void)hipStreamSynchronize(g_eng2.st);
+        for (auto &d : done) (void)hipEventDestroy(d.first);
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        throw;
     }
+    for (auto &d : done) (void)hipEventDestroy(d.first);
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    if (two) FR3D_HIP(hipStreamSynchronize(g_eng2.st));
     FR3D_HIP(hipStreamSynchronize(e.st));
 }
 
@@ -1403,47 +1448,65 @@ int fr3d_init(int device)
     FR3D_CHECK(n > 0, "no HIP device visible");
     FR3D_CHECK(device >= 0 && device < n, "device index out of range");
     FR3D_HIP(hipSetDevice(device));
-    FR3D_HIP(hipStreamCreateWithFlags(&g_eng.st, hipStreamNonBlocking));
-    g_eng.device = device;
-    std::memset(g_eng.acc, 0, sizeof(g_eng.acc));
-    g_eng.inited = true;
+    for (Engine *en : {&g_eng, &g_eng2}) {
+        FR3D_HIP(hipStreamCreateWithFlags(&en->st, hipStreamNonBlocking));
+        en->device = device;
+        std::memset(en->acc, 0, sizeof(en->acc));
+        en->inited = true;
+    }
+    if (const char *v = std::getenv("FR3D_LANES")) g_lanes = std::atoi(v) == 2 ? 2 : 1;
     FR3D_CATCH
+}
+
+static void release_engine(Engine &en)
+{
+    if (!en.inited) return;
+    (void)hipStreamSynchronize(en.st);
+    for (auto &kv : en.bufs) kv.second.release();
+    en.bufs.clear();
+    for (auto &kv : en.tables) {
+        (void)hipFree(kv.second.idx);
+        (void)hipFree(kv.second.wt);
+    }
+    en.tables.clear();
+    for (auto &kv : en.scheds) free_sor_schedule(kv.second);
+    en.scheds.clear();
+    for (auto &kv : en.chain_scheds) free_sor_chain_schedule(kv.second);
+    en.chain_scheds.clear();
+    for (auto &kv : en.gkernels) (void)hipFree(kv.second.first);
+    en.gkernels.clear();
+    for (auto &kv : en.compacts) {
+        (void)hipFree(kv.second.pb);
+        (void)hipFree(kv.second.cp);
+    }
+    en.compacts.clear();
+    for (auto &s : en.spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    en.spans.clear();
+    for (auto ev : en.ev_pool) (void)hipEventDestroy(ev);
+    en.ev_pool.clear();
+    (void)hipStreamDestroy(en.st);
+    en.st = nullptr;
+    en.inited = false;
+    en.device = -1;
 }
 
 void fr3d_shutdown(void)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!g_eng.inited) return;
-    (void)hipStreamSynchronize(g_eng.st);
-    for (auto &kv : g_eng.bufs) kv.second.release();
-    g_eng.bufs.clear();
-    for (auto &kv : g_eng.tables) {
-        (void)hipFree(kv.second.idx);
-        (void)hipFree(kv.second.wt);
-    }
-    g_eng.tables.clear();
-    for (auto &kv : g_eng.scheds) free_sor_schedule(kv.second);
-    g_eng.scheds.clear();
-    for (auto &kv : g_eng.chain_scheds) free_sor_chain_schedule(kv.second);
-    g_eng.chain_scheds.clear();
-    for (auto &kv : g_eng.gkernels) (void)hipFree(kv.second.first);
-    g_eng.gkernels.clear();
-    for (auto &kv : g_eng.compacts) {
-        (void)hipFree(kv.second.pb);
-        (void)hipFree(kv.second.cp);
-    }
-    g_eng.compacts.clear();
-    for (auto &s : g_eng.spans) {
-        (void)hipEventDestroy(s.a);
-        (void)hipEventDestroy(s.b);
-    }
-    g_eng.spans.clear();
-    for (auto ev : g_eng.ev_pool) (void)hipEventDestroy(ev);
-    g_eng.ev_pool.clear();
-    (void)hipStreamDestroy(g_eng.st);
-    g_eng.st = nullptr;
-    g_eng.inited = false;
-    g_eng.device = -1;
+    release_engine(g_eng2);
+    release_engine(g_eng);
+    g_cur = &g_eng;
+}
+
+int fr3d_set_lanes(int lanes)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    const int prev = g_lanes;
+    if (lanes == 1 || lanes == 2) g_lanes = lanes;
+    return prev;
 }
 
 int fr3d_get_displacement_dev(const fr3d_params *p, const float *fixed, const float *moving, int Z, int Y,
@@ -2125,17 +2188,19 @@ int fr3d_sync(void)
 
 static void fold_spans()
 {
-    Engine &e = g_eng;
-    if (e.spans.empty()) return;
-    FR3D_HIP(hipStreamSynchronize(e.st));
-    for (auto &s : e.spans) {
-        float ms = 0.0f;
-        FR3D_HIP(hipEventElapsedTime(&ms, s.a, s.b));
-        e.acc[s.kid].ms += ms;
-        e.ev_pool.push_back(s.a);
-        e.ev_pool.push_back(s.b);
+    for (Engine *en : {&g_eng, &g_eng2}) {
+        Engine &e = *en;
+        if (e.spans.empty()) continue;
+        FR3D_HIP(hipStreamSynchronize(e.st));
+        for (auto &s : e.spans) {
+            float ms = 0.0f;
+            FR3D_HIP(hipEventElapsedTime(&ms, s.a, s.b));
+            e.acc[s.kid].ms += ms;
+            e.ev_pool.push_back(s.a);
+            e.ev_pool.push_back(s.b);
+        }
+        e.spans.clear();
     }
-    e.spans.clear();
 }
 
 int fr3d_prof_enable(int on)
@@ -2143,7 +2208,7 @@ int fr3d_prof_enable(int on)
     FR3D_TRY
     ensure_init();
     fold_spans();
-    g_eng.prof = on != 0;
+    g_eng.prof = g_eng2.prof = on != 0;
     FR3D_CATCH
 }
 int fr3d_prof_reset(void)
@@ -2152,6 +2217,7 @@ int fr3d_prof_reset(void)
     ensure_init();
     fold_spans();
     std::memset(g_eng.acc, 0, sizeof(g_eng.acc));
+    std::memset(g_eng2.acc, 0, sizeof(g_eng2.acc));
     FR3D_CATCH
 }
 int fr3d_stream_probe(size_t n_floats, int reps, double *gbytes_per_s)
@@ -2205,7 +2271,15 @@ int fr3d_prof_get(fr3d_kernel_stat *out)
     ensure_init();
     FR3D_CHECK(out, "NULL pointer");
     fold_spans();
-    std::memcpy(out, g_eng.acc, sizeof(g_eng.acc));
+    // both lanes added up: with two lanes the spans of one lane run while the other lane's kernels share the device, so
+    // the times are per-lane stream times, not exclusive kernel times (per-kernel accounting: fr3d_set_lanes(1))
+    for (int k = 0; k < FR3D_K_COUNT; k++) {
+        out[k] = g_eng.acc[k];
+        out[k].ms += g_eng2.acc[k].ms;
+        out[k].algo_bytes += g_eng2.acc[k].algo_bytes;
+        out[k].launches += g_eng2.acc[k].launches;
+        out[k].units += g_eng2.acc[k].units;
+    }
     FR3D_CATCH
 }
 
