@@ -74,6 +74,21 @@ def expand_weight(weight, p, m, n, n_channels):
     return weight
 
 
+def is_default_weight(weight, n_channels):
+    """True for weights that expand to the constant 1/C the reference builds for weight=None (core/optical_flow_3d.py:351-381:
+    a 1-D weight is completed with 1/C, cut to C entries and normalised): callers then pass NULL and the engine makes the
+    constant itself instead of receiving a (Z,Y,X,C) array of it."""
+    if weight is None:
+        return True
+    w = np.asarray(weight, dtype=np.float64)
+    if w.ndim != 1 or w.size == 0:
+        return False
+    if len(w) < n_channels:
+        w = np.concatenate([w, np.full(n_channels - len(w), 1.0 / n_channels)])
+    w = w[:n_channels]
+    return bool(w.sum() != 0 and np.all(w / w.sum() == 1.0 / n_channels))
+
+
 def _f32c(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

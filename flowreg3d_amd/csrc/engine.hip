@@ -4,6 +4,7 @@
 // include/flowreg3d_hip.h.  Everything between the entry copy-in and the exit copy-out stays in
 // HBM; the only host work per level is the (cached) table build and kernel launches.
 #include <cmath>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstdio>
@@ -1734,6 +1735,19 @@ int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const 
     FR3D_CHECK(ref_dtype == FR3D_F32 || ref_dtype == FR3D_F64, "reference_raw must be float32 or float64");
     const size_t nv = (size_t)Z * Y * X;
     const size_t rsz = dtype_size(raw_dtype), fsz = dtype_size(ref_dtype);
+#ifdef FR3D_EXPERIMENTS  // FR3D_HOST_TRACE=1: milliseconds since entry of every phase of this call, on stderr
+    const bool trace = getenv("FR3D_HOST_TRACE") != nullptr;
+    const auto t_entry = std::chrono::steady_clock::now();
+    std::mutex trace_mu;
+    auto mark = [&](const char *what, int k) {
+        if (!trace) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count();
+        std::lock_guard<std::mutex> lk(trace_mu);
+        fprintf(stderr, "[host trace] %8.2f ms  %s %d\n", ms, what, k);
+    };
+#else
+    auto mark = [](const char *, int) {};
+#endif
     Staged s;
     const float *drp = (const float *)s.up(ref_proc, nv * C * 4);
     const void *drr = s.up(ref_raw, nv * C * fsz);
@@ -1767,7 +1781,9 @@ int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const 
     int min_level = p->min_level;
     std::vector<Level> lv = make_schedule(Z, Y, X, p->eta, p->levels, min_level);
     RefPyramid rp;
+    mark("reference arrays uploaded", 0);
     if (T > 0) build_ref_pyramid(g_eng, lv, drp, dwt, Z, Y, X, C, rp, "pb_");
+    mark("reference pyramid enqueued", 0);
     std::mutex mu;
     std::condition_variable cv;
     int uploaded = 0, computed = 0;  // windows finished by each side
@@ -1788,6 +1804,7 @@ int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const 
                 FR3D_HIP(hipMemcpyAsync(dbr[q], (const char *)batch_raw + o * rsz, nv * C * rsz * (size_t)nt,
                                         hipMemcpyHostToDevice, cs));
                 FR3D_HIP(hipStreamSynchronize(cs));
+                mark("window uploaded", k);
                 std::lock_guard<std::mutex> lk(mu);
                 uploaded = k + 1;
                 cv.notify_all();
@@ -1802,6 +1819,7 @@ int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const 
                 pinned_fl = hipHostRegister(flows_out, fl_bytes, hipHostRegisterDefault) == hipSuccess;
                 pinned_re = hipHostRegister(registered_out, re_bytes, hipHostRegisterDefault) == hipSuccess;
                 (void)hipGetLastError();
+                mark("output arrays pinned", 0);
             }
             for (int k = 0; k < nwin; k++) {
                 {
@@ -1815,6 +1833,7 @@ int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const 
                 FR3D_HIP(hipMemcpyAsync((char *)registered_out + (size_t)k * win * nv * C * rsz, dre[q],
                                         nv * C * rsz * (size_t)nt, hipMemcpyDeviceToHost, cs));
                 FR3D_HIP(hipStreamSynchronize(cs));
+                mark("window downloaded", k);
                 if (k + nset < nwin) upload(k + nset);
             }
         } catch (...) {
@@ -1826,6 +1845,7 @@ int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const 
         if (cs) (void)hipStreamDestroy(cs);
         if (pinned_fl) (void)hipHostUnregister(flows_out);
         if (pinned_re) (void)hipHostUnregister(registered_out);
+        mark("copier done", 0);
     });
     std::exception_ptr main_error;
     try {
@@ -1838,6 +1858,7 @@ int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const 
             const int q = k % nset;
             process_batch_dev(p, dbp[q], dbr[q], raw_dtype, drp, drr, ref_dtype, dwi, dwt, count_of(k), Z, Y, X, C, order,
                               dfl[q], dre[q], progress, user, &rp);  // returns with the engine stream drained
+            mark("window computed", k);
             std::lock_guard<std::mutex> lk(mu);
             computed = k + 1;
             cv.notify_all();
@@ -1849,6 +1870,7 @@ int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const 
         cv.notify_all();
     }
     copier.join();
+    mark("exit", 0);
     if (main_error) std::rethrow_exception(main_error);
     if (copier_error) std::rethrow_exception(copier_error);
     FR3D_CATCH

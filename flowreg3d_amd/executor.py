@@ -26,7 +26,7 @@ from typing import Any, Callable, Dict, Optional, Tuple
 import numpy as np
 
 from . import _lib
-from .core import _order_of, expand_weight
+from .core import _order_of, expand_weight, is_default_weight
 
 
 _RAW_CODES = {np.dtype(np.float32): _lib.F32, np.dtype(np.float64): _lib.F64, np.dtype(np.uint8): _lib.U8,
@@ -137,7 +137,7 @@ class HipExecutor3D:
                                   fp.get("min_level", 0), fp.get("levels", 50), fp.get("eta", 0.8), a_smooth,
                                   fp.get("a_data", 0.45), nc,
                                   None if fp.get("solver_fp64") is None else int(fp["solver_fp64"]))
-        wt = expand_weight(fp.get("weight", None), Z, Y, X, nc)
+        wt = None if is_default_weight(fp.get("weight", None), nc) else expand_weight(fp.get("weight", None), Z, Y, X, nc)
 
         def f32(a, shape):
             a = np.ascontiguousarray(a, dtype=np.float32)
