@@ -112,7 +112,7 @@ def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=2
     if fixed.ndim != 4 or moving.shape != fixed.shape:
         raise ValueError("fixed and moving must have the same (Z,Y,X[,C]) shape")
     p, m, n, nc = fixed.shape
-    wt = expand_weight(weight, p, m, n, nc)
+    wt = None if is_default_weight(weight, nc) else expand_weight(weight, p, m, n, nc)
     params = _lib.make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth, a_data, nc,
                               solver_fp64)
     f32, m32 = _f32c(fixed), _f32c(moving)
@@ -216,7 +216,7 @@ def get_displacement_verify(fixed, moving, alpha=(2, 2, 2), update_lag=10, itera
     if float(a_smooth) != 1.0:
         raise NotImplementedError("the verification mode covers the a_smooth == 1 solver")
     p, m, n, nc = fixed.shape
-    wt = expand_weight(weight, p, m, n, nc)
+    wt = None if is_default_weight(weight, nc) else expand_weight(weight, p, m, n, nc)
     params = _lib.make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth, a_data, nc, 2)
     f32, m32 = _f32c(fixed), _f32c(moving)
     u32 = None
