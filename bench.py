@@ -16,7 +16,8 @@ core and all cores).  At N = 1 the default run adds two legs to the same line, a
 the headline workload: `host_path` (NumPy arrays in, NumPy arrays out through fr3d_process_batch: the
 PCIe-inclusive rate of the drop-in entry, never `value`) and `cfg3` (the 512^3 six-level configuration,
 4 timed steps at lock-step batch 4, with its own `roofline`) and `a_smooth_0.5` (the psi_smooth solver path on
-the cfg2 geometry) and `two_lanes` (the headline workload with fr3d_set_lanes(2)); `--no-extras` skips them.
+the cfg2 geometry); `--no-extras` skips them.  The timed region runs the library's default of two engine lanes; `one_lane`
+is the profiled one-lane pass right after it, on which `roofline` is measured (--lanes 1: the timed region itself).
 """
 import argparse
 import ctypes as C
@@ -200,9 +201,14 @@ def resolved_mode(solver_fp64, nvox, channels=1, a_smooth=1.0):
 
 
 def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, world, dist, dev_index, fast_inputs,
-            a_smooth=1.0):
+            a_smooth=1.0, lanes=2):
     """Warm up, condition, time EXACTLY K steps (volumes per rank) of `workload`; -> dict of results.
-    Inputs are generated once and are resident in HBM before the timed region starts."""
+    Inputs are generated once and are resident in HBM before the timed region starts.
+    lanes = 2 (the library's default): the timed region runs two engine lanes (two lock-step half batches in flight on two
+    HIP streams); the per-kernel HIP-event times -- `roofline`, `kernel_ms_per_step` -- are then taken on a profiled pass
+    of the same K steps directly after it, which the library runs on ONE lane (the event spans of two lanes overlap and
+    are not kernel times).  lanes = 1: the timed region itself is the profiled pass."""
+    lib.fr3d_set_lanes(lanes)
     from flowreg3d_amd.synthetic import fast_pair, flow_gt, texture
     Z, Y, X, levels, desc = WORKLOADS[workload]
     nv = Z * Y * X
@@ -285,9 +291,20 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
             lib.fr3d_sync()
     barrier()
     t0 = time.perf_counter()
-    run(W, K, True)
+    run(W, K, lanes == 1)
     barrier()
     elapsed = time.perf_counter() - t0
+    one_lane = None
+    if lanes != 1:
+        run(W, K, True)  # the one-lane workspace (twice the lock-step batch per lane) is allocated here, untimed
+        lib.fr3d_sync()
+        t1 = time.perf_counter()
+        run(W, K, True)  # run() resets the brackets: the statistics below are this pass alone
+        lib.fr3d_sync()
+        serial = time.perf_counter() - t1
+        one_lane = {"value": K / serial, "unit": "volumes/sec per GPU", "ms_per_step": 1e3 * serial / K,
+                    "what": "the same K steps on one engine lane with profiling brackets, directly after the timed region: "
+                            "the pass `roofline`, `kernel_ms_per_step` and `roofline_stages` are measured on"}
     stats = _lib.prof_get()
     lib.fr3d_prof_enable(0)
     ran = int(lib.fr3d_last_solver_mode())  # what the library actually resolved FR3D_SOLVER_AUTO to
@@ -301,7 +318,8 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
         per_rank = [float(x) for x in every]
         elapsed = max(per_rank)
     par, par_src = parity_record(workload, mode, not fast_inputs)
-    res = {"elapsed": elapsed, "stats": stats, "batch_vols": batch_vols, "desc": desc, "mode": mode,
+    res = {"elapsed": elapsed, "stats": stats, "batch_vols": batch_vols, "desc": desc, "mode": mode, "lanes": lanes,
+           "one_lane": one_lane,
            "parity_mean_epe_vs_cpu": par, "parity_source": par_src,
            "per_rank_volumes_per_sec": None if per_rank is None else [round(K / t, 3) for t in per_rank],
            "broadcast": None if bcast_ms is None else {"bytes": nv * 4, "ms": round(bcast_ms, 3),
@@ -344,7 +362,10 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
                            "traffic": traffic, "traffic_source": traffic_source,
                            "algo_bytes_per_launch": sor["algo_bytes"] / max(sor["launches"], 1),
                            "avg_launch_us": 1e3 * sor["ms"] / max(sor["launches"], 1),
-                           "launches": sor["launches"]}
+                           "launches": sor["launches"],
+                           "measured_on": "the timed region (one engine lane)" if lanes == 1 else
+                                          "a profiled one-lane pass of the same K steps directly after the timed region (see `one_lane`); "
+                                          "the timed region runs two lanes, whose kernels overlap in time"}
         res["kernel_ms_per_step"] = {k: round(v["ms"] / K, 3) for k, v in stats.items()}
         # the other stages of the path against the same HBM roofline, algorithmic bytes as in
         # DESIGN.md section 5 (warp: 24 B/voxel; the median is compute-bound and listed for completeness)
@@ -405,6 +426,9 @@ def main():
     ap.add_argument("--a-smooth", type=float, default=1.0,
                     help="smoothness exponent (1.0 = the pipeline's OFOptions default and every BASELINE configuration; any "
                          "other value, e.g. get_displacement's own default 0.5, runs the psi_smooth solver path)")
+    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
+                    help="engine lanes of the timed region (fr3d_set_lanes; 2 = the library's default).  Per-kernel times are "
+                         "always taken on one lane: with 2 on a profiled pass directly after the timed region")
     ap.add_argument("--condition", type=float, default=30.0,
                     help="seconds of untimed warm-up work before the timed steps (0 = only the W warm-up steps)")
     args = ap.parse_args()
@@ -442,7 +466,7 @@ def main():
     lib = _lib.init(dev_index)
     K, W = args.steps, args.warmup
     m = measure(lib, _lib, args.workload, K, W, args.batch, args.condition, args.solver_fp64, rank, world, dist,
-                dev_index, fast_inputs=args.workload == "cfg3", a_smooth=args.a_smooth)
+                dev_index, fast_inputs=args.workload == "cfg3", a_smooth=args.a_smooth, lanes=args.lanes)
 
     if rank == 0:
         elapsed = m["elapsed"]
@@ -474,6 +498,7 @@ def main():
                        "parity_mean_epe_vs_cpu_path": m["parity_mean_epe_vs_cpu"], "parity_source": m["parity_source"],
                        "per_rank_volumes_per_sec": m["per_rank_volumes_per_sec"], "broadcast": m["broadcast"],
                        "volumes_per_gpu_per_step": 1, "lockstep_batch": m["batch_vols"],
+                       "engine_lanes": f"{m['lanes']} (fr3d_set_lanes; the lock-step batch is split between the lanes)",
                        "untimed_conditioning_s": args.condition if W > 0 else 0.0,
                        "sharding": f"volume-per-GPU x{world}",
                        "world_size": world, "dist_backend": backend if world > 1 else "none (single process)",
@@ -481,6 +506,7 @@ def main():
                                       "step times, timing only)" if world > 1 else "none",
                        "device": lib.fr3d_device_info().decode()},
             "roofline": m["roofline"],
+            "one_lane": m["one_lane"],
             "kernel_ms_per_step": m["kernel_ms_per_step"],
             "roofline_stages": m["roofline_stages"],
         }
@@ -496,41 +522,28 @@ def main():
                                            ("cfg3_fp32_storage", "cfg3", 1, 5.0, 4), ("cfg3_fp64_storage", "cfg3", 2, 5.0, 4)):
                 _lib.shutdown()
                 lib = _lib.init(dev_index)
-                c3 = measure(lib, _lib, wl, nst, 1, 0, cond, md, 0, 1, None, dev_index, fast_inputs=wl == "cfg3")
+                c3 = measure(lib, _lib, wl, nst, 1, 0, cond, md, 0, 1, None, dev_index, fast_inputs=wl == "cfg3", lanes=args.lanes)
                 out[key] = {"workload": f"{wl}: {c3['desc']}; same solver parameters", "value": nst / c3["elapsed"],
                             "unit": "volumes/sec", "steps": nst, "warmup": 1, "ms_per_step": 1e3 * c3["elapsed"] / nst,
                             "lockstep_batch": c3["batch_vols"], "untimed_conditioning_s": cond,
                             "dtype": "f32" if c3["mode"] == 0 else "f64",
                             "solver": SOLVER_NAMES[c3["mode"]] + (" (library's automatic choice)" if md < 0 else " (forced)"),
                             "parity_mean_epe_vs_cpu_path": c3["parity_mean_epe_vs_cpu"], "parity_source": c3["parity_source"],
-                            "roofline": c3["roofline"],
+                            "roofline": c3["roofline"], "one_lane": c3["one_lane"],
                             "kernel_ms_per_step": c3["kernel_ms_per_step"], "roofline_stages": c3["roofline_stages"]}
             # (3) the psi_smooth solver path (a_smooth != 1; get_displacement's own default is 0.5, no BASELINE
             # configuration uses it): cfg2 geometry, same parameters otherwise
             _lib.shutdown()
             lib = _lib.init(dev_index)
             sm = measure(lib, _lib, "cfg2", 8, 1, 0, 0.0, args.solver_fp64, 0, 1, None, dev_index, fast_inputs=True,
-                         a_smooth=0.5)
+                         a_smooth=0.5, lanes=args.lanes)
             out["a_smooth_0.5"] = {"workload": "cfg2 geometry with a_smooth=0.5 (psi_smooth re-evaluated every iteration)",
                                    "value": 8 / sm["elapsed"], "unit": "volumes/sec", "steps": 8, "warmup": 1,
                                    "ms_per_step": 1e3 * sm["elapsed"] / 8, "lockstep_batch": sm["batch_vols"],
                                    "solver": SOLVER_NAMES[sm["mode"]], "parity_mean_epe_vs_cpu_path": parity_record("cfg2_asmooth05", sm["mode"], False)[0],
                                    "parity_source": parity_record("cfg2_asmooth05", sm["mode"], False)[1],
-                                   "roofline": sm["roofline"], "kernel_ms_per_step": sm["kernel_ms_per_step"]}
-            # (4) two engine lanes (fr3d_set_lanes(2): lock-step batches of 4 alternate between two streams, so that the
-            # stages beside the sweep run under the other lane's sweep) on the headline workload -- the headline itself
-            # stays on one lane: per-kernel times of overlapping lanes are not exclusive kernel times
-            _lib.shutdown()
-            lib = _lib.init(dev_index)
-            lib.fr3d_set_lanes(2)
-            try:
-                tl = measure(lib, _lib, "cfg2", 8, 1, 0, 8.0, args.solver_fp64, 0, 1, None, dev_index, fast_inputs=False)
-            finally:
-                lib.fr3d_set_lanes(1)
-            out["two_lanes"] = {"workload": "cfg2, fr3d_set_lanes(2): two lock-step batches of 4 in flight on two HIP streams",
-                                "value": 8 / tl["elapsed"], "unit": "volumes/sec", "steps": 8, "warmup": 1,
-                                "ms_per_step": 1e3 * tl["elapsed"] / 8, "vs_one_lane": (8 / tl["elapsed"]) / out["value"],
-                                "results": "bit-identical to one lane (tests/test_gpu_executor.py)"}
+                                   "roofline": sm["roofline"], "one_lane": sm["one_lane"],
+                                   "kernel_ms_per_step": sm["kernel_ms_per_step"]}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

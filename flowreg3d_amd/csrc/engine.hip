@@ -322,8 +322,8 @@ static Engine g_eng;
 // compute-bound stages of one lane (median, warp, motion tensor, the coarse levels' short launches) run under the
 // other lane's sweep.  Everything else (single-volume entries, preprocessing, statistics) runs on lane 0.
 static Engine g_eng2;
-static int g_lanes = 1;
-static Engine *g_cur = &g_eng;  // the lane the stage wrappers below enqueue on (calls are serialised by g_mu)
+static int g_lanes = 2;
+static thread_local Engine *g_cur = &g_eng;  // the lane the stage wrappers below enqueue on: lane 1 is driven by a host thread of its own
 static std::recursive_mutex g_mu;
 static thread_local std::string g_err;
 
@@ -1151,66 +1151,110 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     g_fast_path = p->a_smooth == 1.0;
     int B = T > 0 ? pick_batch(T, lv, C) : 1;
     // two lanes: each takes lock-step batches of half the size (same workspace in total), alternately
-    const bool two = g_lanes == 2 && g_eng2.inited && T >= 2 && B >= 2;
+    // (profiling brackets imply one lane: the HIP-event spans of two lanes overlap and are not kernel times)
+    const bool two = g_lanes == 2 && g_eng2.inited && !e.prof && T >= 2 && B >= 2;
     if (two) B = cdiv(B, 2);
+    else
+        for (auto &kv : g_eng2.bufs) kv.second.release();  // one lane: the other lane's workspace is not reusable here
     const int reserve = g_batch_hint > 0 ? std::max(1, pick_batch(g_batch_hint, lv, C) / (two ? 2 : 1)) : B;
-    hipEvent_t ev_start = nullptr;
-    std::vector<std::pair<hipEvent_t, int>> done;  // two lanes: completion event and volume count of every batch
-    if (two) {
-        // lane 1 starts after everything enqueued on lane 0 so far: the caller's inputs and the reference pyramid
-        FR3D_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
-        FR3D_HIP(hipEventRecord(ev_start, e.st));
-        FR3D_HIP(hipStreamWaitEvent(g_eng2.st, ev_start, 0));
-    }
+    // the solver mode is settled here, once: the lanes then never look at the memory budget (and at each other's
+    // workspace tables) while they run
+    fr3d_params pr = *p;
+    pr.solver_fp64 = resolve_mode(*p, C, Z, Y, X, lv);
     // T volumes in ceil(T/B) lock-step batches of (nearly) equal size: 10 volumes at B = 4 run as
     // 4+3+3, not 4+4+2 (the shared launches amortise best over evenly filled batches)
-    int chunks_left = T > 0 ? cdiv(T, B) : 0;
-    int chunk = 0;
-    try {
-        for (int t0 = 0, nb = 0; t0 < T; t0 += nb, chunks_left--, chunk++) {
+    struct Chunk { int t0, nb; };
+    std::vector<Chunk> chunks;
+    {
+        int chunks_left = T > 0 ? cdiv(T, B) : 0;
+        for (int t0 = 0, nb = 0; t0 < T; t0 += nb, chunks_left--) {
             nb = cdiv(T - t0, chunks_left);
-            Engine &lane = two && (chunk & 1) ? g_eng2 : e;
-            std::vector<const float *> mov(nb);
-            std::vector<float *> fl(nb);
-            for (int b = 0; b < nb; b++) {
-                mov[b] = batch_proc + (size_t)(t0 + b) * nv * C;
-                fl[b] = flows_out + (size_t)(t0 + b) * nv * 3;
-            }
-            get_displacement_core(lane, *p, lv, min_level, rp, nb, mov.data(), Z, Y, X, C, w_init, fl.data(), reserve);
-            g_cur = &lane;
-            for (int b = 0; b < nb; b++) {
-                const size_t o = (size_t)(t0 + b) * nv * C * esz;
-                warp_raw((const char *)batch_raw + o, raw_dtype, fl[b], ref_raw, ref_dtype, Z, Y, X, C, order,
-                         (char *)registered_out + o);
-            }
-            g_cur = &g_eng;
-            if (two) {
-                // nothing waits here: the host runs ahead and both lanes stay busy; progress is reported below
-                hipEvent_t ev;
-                FR3D_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                done.emplace_back(ev, nb);
-                FR3D_HIP(hipEventRecord(ev, lane.st));
-            } else if (progress) {
-                FR3D_HIP(hipStreamSynchronize(e.st));
-                for (int b = 0; b < nb; b++) progress(1, user);
-            }
+            chunks.push_back({t0, nb});
         }
-        for (auto &d : done) {
-            FR3D_HIP(hipEventSynchronize(d.first));
-            if (progress)
-                for (int b = 0; b < d.second; b++) progress(1, user);
+    }
+    auto run_chunk = [&](Engine &lane, const Chunk &c) {
+        std::vector<const float *> mov(c.nb);
+        std::vector<float *> fl(c.nb);
+        for (int b = 0; b < c.nb; b++) {
+            mov[b] = batch_proc + (size_t)(c.t0 + b) * nv * C;
+            fl[b] = flows_out + (size_t)(c.t0 + b) * nv * 3;
         }
-    } catch (...) {
+        get_displacement_core(lane, pr, lv, min_level, rp, c.nb, mov.data(), Z, Y, X, C, w_init, fl.data(), reserve);
+        g_cur = &lane;
+        for (int b = 0; b < c.nb; b++) {
+            const size_t o = (size_t)(c.t0 + b) * nv * C * esz;
+            warp_raw((const char *)batch_raw + o, raw_dtype, fl[b], ref_raw, ref_dtype, Z, Y, X, C, order,
+                     (char *)registered_out + o);
+        }
         g_cur = &g_eng;
-        (void)hipStreamSynchronize(g_eng2.st);
-        for (auto &d : done) (void)hipEventDestroy(d.first);
-        if (ev_start) (void)hipEventDestroy(ev_start);
+    };
+    if (!two) {
+        for (const Chunk &c : chunks) {
+            run_chunk(e, c);
+            if (progress) {
+                FR3D_HIP(hipStreamSynchronize(e.st));
+                for (int b = 0; b < c.nb; b++) progress(1, user);
+            }
+        }
+        FR3D_HIP(hipStreamSynchronize(e.st));
+        return;
+    }
+    // Two lanes.  Lane 1 starts behind an event that covers everything enqueued on lane 0 so far (the caller's inputs,
+    // the reference pyramid) and is fed by a host thread of its own: a batch is thousands of launches, and one thread
+    // feeding both streams would block on the first stream's full queue while the second runs dry.  Each thread waits
+    // for its batches in order and reports their volumes (the callback is serialised; it may be called from either thread).
+    hipEvent_t ev_start = nullptr;
+    FR3D_HIP(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+    std::exception_ptr err0, err1;
+    try {
+        FR3D_HIP(hipEventRecord(ev_start, e.st));
+        FR3D_HIP(hipStreamWaitEvent(g_eng2.st, ev_start, 0));
+    } catch (...) {
+        (void)hipEventDestroy(ev_start);
         throw;
     }
-    for (auto &d : done) (void)hipEventDestroy(d.first);
-    if (ev_start) (void)hipEventDestroy(ev_start);
-    if (two) FR3D_HIP(hipStreamSynchronize(g_eng2.st));
-    FR3D_HIP(hipStreamSynchronize(e.st));
+    const int device = e.device;
+    std::mutex progress_mu;
+    auto feed = [&](Engine &lane, int parity, std::exception_ptr &err) {
+        std::vector<std::pair<hipEvent_t, int>> pending;  // completion event and volume count of this lane's batches
+        auto report = [&](size_t upto) {  // wait for this lane's batches [reported, upto) and report them
+            for (; !pending.empty() && upto > 0; upto--) {
+                FR3D_HIP(hipEventSynchronize(pending.front().first));
+                if (progress) {
+                    std::lock_guard<std::mutex> lk(progress_mu);
+                    for (int b = 0; b < pending.front().second; b++) progress(1, user);
+                }
+                (void)hipEventDestroy(pending.front().first);
+                pending.erase(pending.begin());
+            }
+        };
+        try {
+            FR3D_HIP(hipSetDevice(device));
+            for (size_t i = 0; i < chunks.size(); i++) {
+                if ((int)(i & 1) != parity) continue;
+                run_chunk(lane, chunks[i]);
+                hipEvent_t ev;
+                FR3D_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                pending.emplace_back(ev, chunks[i].nb);
+                FR3D_HIP(hipEventRecord(ev, lane.st));
+                // with the next batch already in the queue, wait for the one before it: progress arrives one batch late
+                // and the host never runs more than two batches ahead of the device
+                if (pending.size() > 1) report(pending.size() - 1);
+            }
+            report(pending.size());
+            FR3D_HIP(hipStreamSynchronize(lane.st));
+        } catch (...) {
+            err = std::current_exception();
+            (void)hipStreamSynchronize(lane.st);
+            for (auto &pe : pending) (void)hipEventDestroy(pe.first);
+        }
+    };
+    std::thread other(feed, std::ref(g_eng2), 1, std::ref(err1));
+    feed(e, 0, err0);
+    other.join();
+    (void)hipEventDestroy(ev_start);
+    if (err0) std::rethrow_exception(err0);
+    if (err1) std::rethrow_exception(err1);
 }
 
 // ---- f-4 update_reference (compensate_recording_3D.py:395-429) -------------------------------------
@@ -1455,7 +1499,7 @@ int fr3d_init(int device)
         std::memset(en->acc, 0, sizeof(en->acc));
         en->inited = true;
     }
-    if (const char *v = std::getenv("FR3D_LANES")) g_lanes = std::atoi(v) == 2 ? 2 : 1;
+    if (const char *v = std::getenv("FR3D_LANES")) g_lanes = std::atoi(v) == 1 ? 1 : 2;
     FR3D_CATCH
 }
 

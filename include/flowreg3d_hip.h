@@ -81,13 +81,15 @@ const char *fr3d_device_info(void);
  * default 8, env FR3D_BATCH).  Also reserves solver workspace for that many volumes on first use,
  * so a later full batch does not reallocate.  0 restores the default. */
 int fr3d_set_batch(int nvol);
-/* Engine lanes of fr3d_process_batch* (1 or 2; default 1; returns the previous value).  With 2 the lock-step batches of a
- * series are dealt alternately to two engine lanes (two HIP streams, each with its own workspace; batches of half the
- * size, same memory in total), so that the compute-bound stages of one batch -- median, warps, motion tensor, the short
- * launches of the coarse levels -- run under the other batch's sweep.  Results are bit-identical to one lane.  The
+/* Engine lanes of fr3d_process_batch* (1 or 2; default 2, env FR3D_LANES; returns the previous value).  With 2 the
+ * lock-step batches of a series are dealt alternately to two engine lanes -- two HIP streams, each with its own workspace
+ * (batches of half the size: the same memory in total), lane 1 fed by a host thread of its own -- so that the stages of
+ * one batch that do not fill the memory system (median, warps, motion tensor, the short launches of the coarse levels,
+ * the ramp and tail of every sweep launch) run under the other batch's sweep: +9..12 % at 256^3.  Results are
+ * bit-identical to one lane.  The progress callback is serialised but may come from either host thread.  The
  * reference's counterpart is its executor's worker pool (parallelization/multiprocessing_3d.py:286-318: several
- * batches in flight).  fr3d_prof_get adds both lanes' stream times, which overlap: keep one lane for per-kernel
- * accounting. */
+ * batches in flight).  While profiling brackets are on (fr3d_prof_enable(1)) a call runs on ONE lane: the event spans
+ * of two lanes overlap and would not be kernel times. */
 int fr3d_set_lanes(int lanes);
 
 /* ---- the hot path --------------------------------------------------------------------- */

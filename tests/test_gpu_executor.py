@@ -166,9 +166,10 @@ def test_errors_surface_as_exceptions_and_leave_the_engine_usable(hip):
 
 @pytest.mark.parametrize("C,a_smooth", [(1, 1.0), (2, 1.0), (1, 0.5)])
 def test_two_engine_lanes_give_the_one_lane_results_bit_for_bit(hip, C, a_smooth):
-    """fr3d_set_lanes(2): the lock-step batches of a series alternate between two engine lanes (two streams, two
-    workspaces); 9 volumes at batch 4 run as 2+2+2+2+1 on lanes 0,1,0,1,0.  Flows, registered volumes and the progress
-    count must equal the one-lane run; a repeat on warm workspaces too."""
+    """Two engine lanes (the default; fr3d_set_lanes(1) = one): the lock-step batches of a series alternate between two
+    engine lanes (two streams, two workspaces, lane 1 fed by a host thread of its own); 9 volumes at batch 4 run as
+    2+2+2+2+1 on lanes 0,1,0,1,0.  Flows, registered volumes and the progress count must equal the one-lane run; a
+    repeat on warm workspaces too."""
     from flowreg3d_amd import _lib
     from flowreg3d_amd.executor import HipExecutor3D
     fixed, batch = _series(T=9, shape=(12, 18, 22), C=C)
@@ -180,6 +181,7 @@ def test_two_engine_lanes_give_the_one_lane_results_bit_for_bit(hip, C, a_smooth
     with HipExecutor3D() as ex:
         lib.fr3d_set_batch(4)
         try:
+            assert lib.fr3d_set_lanes(1) == 2  # two lanes are the default
             reg1, fl1 = ex.process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=fp)
             assert lib.fr3d_set_lanes(2) == 1
             for rep in range(2):
@@ -189,5 +191,5 @@ def test_two_engine_lanes_give_the_one_lane_results_bit_for_bit(hip, C, a_smooth
                 assert sum(calls) == 9
                 assert np.array_equal(fl1, fl2) and np.array_equal(reg1, reg2), rep
         finally:
-            assert lib.fr3d_set_lanes(1) == 2
+            lib.fr3d_set_lanes(2)
             lib.fr3d_set_batch(0)

@@ -150,8 +150,8 @@ def test_device_sink_gives_the_host_path_results(hip, dtype, update_ref):
 
 
 def test_batch_driver_with_two_engine_lanes_is_bit_identical(hip):
-    """fr3d_set_lanes(2) under the whole batch driver (host arrays and device sink): same registered series, flows,
-    running w_init and statistics as with one lane; an invalid lane count leaves the setting alone."""
+    """Two engine lanes (the default) under the whole batch driver (host arrays and device sink): same registered series,
+    flows, running w_init and statistics as with one lane; an invalid lane count leaves the setting alone."""
     from scipy.ndimage import gaussian_filter
     from flowreg3d_amd import _lib
     from flowreg3d_amd.pipeline import BatchMotionCorrectorHip, Options
@@ -162,9 +162,12 @@ def test_batch_driver_with_two_engine_lanes_is_bit_identical(hip):
     video = np.stack([np.roll(ref, (t % 3) - 1, axis=1) * 0.95 + 0.01 * t for t in range(9)], 0).astype(np.float32)
     kw = dict(levels=2, min_level=0, iterations=6, buffer_size=5, weight=[1.0], sigma=[[1.0, 1.0, 1.0, 0.1]])
     lib = _lib.init(0)
-    one = BatchMotionCorrectorHip(Options(**kw))
-    reg1, w1 = one.run(video, ref)
-    assert lib.fr3d_set_lanes(3) == 1 and lib.fr3d_set_lanes(2) == 1  # 3 is ignored
+    assert lib.fr3d_set_lanes(1) == 2
+    try:
+        one = BatchMotionCorrectorHip(Options(**kw))
+        reg1, w1 = one.run(video, ref)
+    finally:
+        assert lib.fr3d_set_lanes(3) == 1 and lib.fr3d_set_lanes(2) == 1  # 3 is ignored
     try:
         two = BatchMotionCorrectorHip(Options(**kw))
         reg2, w2 = two.run(video, ref)
@@ -175,7 +178,7 @@ def test_batch_driver_with_two_engine_lanes_is_bit_identical(hip):
         finally:
             sink.free()
     finally:
-        assert lib.fr3d_set_lanes(1) == 2
+        assert lib.fr3d_set_lanes(2) == 2
     assert np.array_equal(reg1, reg2) and np.array_equal(w1, w2)
     assert np.array_equal(one.w_init, two.w_init) and np.array_equal(one.w_init, dev.w_init)
     np.testing.assert_array_equal(one.stats.mean_disp, two.stats.mean_disp)
