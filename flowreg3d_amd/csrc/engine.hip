@@ -359,6 +359,8 @@ struct Span {
 static void ensure_init()
 {
     if (!g_eng.inited) throw Error("fr3d_init() has not been called (or failed)");
+    // the current device is a per-thread setting: a caller on another host thread than fr3d_init's gets the engine's device
+    FR3D_HIP(hipSetDevice(g_eng.device));
 }
 
 // ---------------------------------------------------------------------------------------------
