@@ -1045,6 +1045,7 @@ static void get_displacement_dev(const fr3d_params *p, const float *fixed, const
     int min_level = p->min_level;
     std::vector<Level> lv = make_schedule(Z, Y, X, p->eta, p->levels, min_level);
     RefPyramid rp;
+    for (auto &kv : g_eng2.bufs) kv.second.release();  // a single volume runs on lane 0: it may need the other lane's memory
     build_ref_pyramid(e, lv, fixed, weight, Z, Y, X, C, rp, "gd_");
     get_displacement_core(e, *p, lv, min_level, rp, 1, &moving, Z, Y, X, C, uvw_init, &flow_out);
     FR3D_HIP(hipStreamSynchronize(e.st));
