@@ -4,6 +4,7 @@
 // include/flowreg3d_hip.h.  Everything between the entry copy-in and the exit copy-out stays in
 // HBM; the only host work per level is the (cached) table build and kernel launches.
 #include <cmath>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -994,7 +995,7 @@ static double solver_budget(const std::vector<Level> &lv, int C)
     return std::min(0.85 * (double)total_b, avail);
 }
 
-static int g_last_mode = -1;  // fr3d_last_solver_mode()
+static std::atomic<int> g_last_mode{-1};  // fr3d_last_solver_mode(); both lanes store the same value
 
 // The solver mode of a call: solver_mode(), except that an AUTOMATIC choice of packed storage falls back to fp32
 // storage when one volume's packed slabs do not fit the device and its fp32 slabs do (one 1024^3 volume: 164 GB of
