@@ -38,19 +38,21 @@ namespace fr3d {
 template <typename R, typename S, int C>
 __global__ void __launch_bounds__(SOR_MAX_THREADS)
 k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__restrict__ ent,
-           const int *__restrict__ lut)
+           const int *__restrict__ lut, int xg)
 {
     const int Z = a.sk.Z, Y = a.sk.Y, X = a.sk.X;
     // blockIdx.x enumerates the tiles of all groups of this launch (schedule built on the host)
     const int vol = blockIdx.y;
-#ifdef FR3D_SOR_XCD
-    // variant build: workgroups are dealt round-robin over the 8 XCDs, so give the ids that share an XCD (equal id % 8)
-    // one contiguous eighth of the tile list (neighbouring row blocks of one plane then meet in one L2)
-    const int q8 = gridDim.x >> 3, r8 = gridDim.x & 7, x8 = blockIdx.x & 7;
-    const int b = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (int)(blockIdx.x >> 3);
-#else
-    const int b = blockIdx.x;
-#endif
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (ids with equal id % 8 share one and its L2),
+    // so in blockIdx order the row blocks of a plane that share halo rows never meet in one L2.  Within every run of
+    // 8 xg tiles an XCD takes xg CONSECUTIVE tiles of the list (a few neighbouring row blocks), while all XCDs stay in
+    // the same neighbourhood of memory; the tail of the list keeps its order; xg = 0: blockIdx order.
+    // (One contiguous eighth of the list per XCD loses 5-7 % at 256^3: profiles/r03/sor_xcd_swizzle_ab.txt.)
+    int b = blockIdx.x;
+    if (xg > 0) {
+        const int run = 8 * xg, full = (int)(gridDim.x / run) * run;
+        if (b < full) b = (b / run) * run + (b & 7) * xg + ((b >> 3) % xg);
+    }
     // find the group: the table gives the entry of the first tile of this tile group, a short
     // forward scan does the rest (a bisection costs ~7 dependent scalar loads before the first
     // vector load can be issued)
@@ -219,6 +221,22 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
     strec<S, 3>(D, c0, out);
 }
 
+// Tiles an XCD takes in a row (k_sor_step's xg).  Measured, alternating on one box (profiles/r03/sor_xcd_group_ab.txt):
+// at 512^3 (rows of up to 512 lanes, 8 tiles per row block) 32 takes the sweep from 0.525 to 0.558 of the roofline with
+// packed storage and from 0.518 to 0.538 with fp64 storage (8: 0.547, 16: 0.55, 64: 0.555); fp32 storage: no gain;
+// at 256^3 every group size LOSES 4 % (0.505 -> 0.485 packed, 0.484 -> 0.462 fp32 storage).  So: levels whose rows
+// reach 384 lanes, packed and fp64 storage.
+template <typename S>
+static int sor_xcd_group(const Skew &sk)
+{
+    int g = (!std::is_same<S, float>::value && std::min(sk.X, sk.Y) >= 384) ? 32 : 0;
+#ifdef FR3D_EXPERIMENTS
+    if (const char *env = getenv("FR3D_SOR_XCD_G"))
+        if (atoi(env) >= 0) g = atoi(env);  // negative: the rule above
+#endif
+    return g;
+}
+
 template <typename R, typename S>
 static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo, const SorChainSched &sc, size_t l)
 {
@@ -228,8 +246,9 @@ static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo,
     const int *lut = sc.lut + sc.lut_first[l];
     const int nent = sc.nent[l];
     const dim3 grid(ntiles, a.nvol > 0 ? a.nvol : 1), block(SOR_BX, sc.by, sc.nch);
+    const int xg = sor_xcd_group<S>(a.sk);
 #define FR3D_SOR_CASE(CH)                                                                                     \
-    case CH: hipLaunchKernelGGL((k_sor_step<R, S, CH>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut); break;
+    case CH: hipLaunchKernelGGL((k_sor_step<R, S, CH>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut, xg); break;
     switch (a.C) {
         FR3D_SOR_CASE(1)
         FR3D_SOR_CASE(2)
@@ -239,7 +258,7 @@ static void launch_step(hipStream_t st, const SorArgsT<S> &a, int tau, int t_lo,
         // (the loop already handles one channel at a time, k_sor_core.h; level_solver_3d.py:356-377 loops over any C)
         default:
             FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
-            hipLaunchKernelGGL((k_sor_step<R, S, 0>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut);
+            hipLaunchKernelGGL((k_sor_step<R, S, 0>), grid, block, 0, st, a, tau, t_lo, nent, ent, lut, xg);
             break;
     }
 #undef FR3D_SOR_CASE
