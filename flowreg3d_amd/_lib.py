@@ -113,6 +113,7 @@ SIGNATURES = {
     "fr3d_prof_get": (C.c_int, [C.POINTER(KernelStat)]),
     "fr3d_stream_probe": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "fr3d_read_probe": (C.c_int, [C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "fr3d_xcd_probe": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib = None

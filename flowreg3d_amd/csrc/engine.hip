@@ -2335,6 +2335,24 @@ int fr3d_read_probe(size_t n_floats, int reps, double *gbytes_per_s)
     *gbytes_per_s = 32.0 * (double)n_floats * reps / ((double)ms * 1e-3) / 1e9;
     FR3D_CATCH
 }
+}  // extern "C"
+namespace fr3d { void launch_xcd_probe(hipStream_t st, int gx, int gy, int *out); }  // k_misc.hip (diagnostic)
+extern "C" {
+int fr3d_xcd_probe(int grid_x, int grid_y, int *xcc_of_block)
+{
+    FR3D_TRY
+    ensure_init();
+    FR3D_CHECK(grid_x > 0 && grid_y > 0 && grid_y <= 65535 && xcc_of_block, "bad xcd_probe arguments");
+    Engine &e = g_eng;
+    Staged s;
+    const size_t n = (size_t)grid_x * grid_y;
+    int *d = (int *)s.alloc(n * sizeof(int));
+    FR3D_HIP(hipMemsetAsync(d, 0xff, n * sizeof(int), e.st));
+    launch_xcd_probe(e.st, grid_x, grid_y, d);
+    FR3D_HIP(hipStreamSynchronize(e.st));
+    FR3D_HIP(hipMemcpy(xcc_of_block, d, n * sizeof(int), hipMemcpyDeviceToHost));
+    FR3D_CATCH
+}
 int fr3d_prof_get(fr3d_kernel_stat *out)
 {
     FR3D_TRY

@@ -193,3 +193,20 @@ void launch_flow_stats(hipStream_t st, const float *flow, int Z, int Y, int X, i
 }
 
 }  // namespace fr3d
+
+// Which XCD each workgroup of a grid_x x grid_y launch runs on (HW_REG_XCC_ID, bits 3:0): a diagnostic for the
+// placement assumption behind the sweep's XCD-aware tile order (ids with equal blockIdx.x % 8 share an XCD).
+namespace fr3d {
+__global__ void k_xcd_probe(int *__restrict__ out)
+{
+    if (threadIdx.x == 0) {
+        const unsigned v = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // hwreg(HW_REG_XCC_ID), all 32 bits
+        out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (int)(v & 0xf);
+    }
+}
+void launch_xcd_probe(hipStream_t st, int gx, int gy, int *out)
+{
+    hipLaunchKernelGGL(k_xcd_probe, dim3(gx, gy), dim3(128), 0, st, out);
+    FR3D_LAUNCH_CHECK();
+}
+}  // namespace fr3d

@@ -298,6 +298,10 @@ int fr3d_stream_probe(size_t n_floats, int reps, double *gbytes_per_s);
 /* Same for a read-only stream (eight arrays of n_floats summed per thread, 32 B per element): the
  * ceiling for a read-heavy kernel such as the SOR sweep. */
 int fr3d_read_probe(size_t n_floats, int reps, double *gbytes_per_s);
+/* Which XCD (0..7, HW_REG_XCC_ID) each workgroup of a grid_x x grid_y launch of 128 threads ran on,
+ * xcc_of_block[y * grid_x + x]: the placement the sweep's XCD-aware tile order assumes (workgroup ids with equal
+ * blockIdx.x % 8 share an XCD) is an observation, not a HIP guarantee -- this lets a test and a user look. */
+int fr3d_xcd_probe(int grid_x, int grid_y, int *xcc_of_block);
 
 #ifdef __cplusplus
 }

@@ -311,3 +311,17 @@ def test_level_solver_accepts_the_engines_own_fp32_grade_tensor(hip):
     bad[0] = bad[0] + 0.1 * (np.abs(bad[0]).max() + 1.0)
     with pytest.raises(ValueError):
         hip.level_solver(*bad, wt, z, z, z, (0.25, 0.25, 0.25), 3, 5, False, 0.45, 1.0, 1.0, 1.0, 1.0)
+
+
+def test_workgroups_with_equal_id_mod_8_share_an_xcd(hip):
+    """The placement the sweep's XCD-aware tile order relies on for SPEED (never for correctness: results are bit-identical
+    under any placement): workgroups are dealt round-robin over the 8 XCDs, so blockIdx.x and blockIdx.x + 8 share one.
+    An observation of this hardware and runtime, not a HIP guarantee -- if it stops holding, revisit sor_xcd_group()."""
+    from flowreg3d_amd import _lib
+    lib = _lib.init(0)
+    for gx, gy in ((4096, 1), (4099, 4)):
+        a = np.full((gy, gx), -1, np.int32)
+        _lib.check(lib.fr3d_xcd_probe(gx, gy, a.ctypes.data))
+        assert a.min() >= 0 and a.max() <= 7
+        assert np.mean(a[:, 8:] == a[:, :-8]) > 0.98, (gx, gy)
+        assert np.bincount(a.reshape(-1), minlength=8).min() > 0.8 * a.size / 8
