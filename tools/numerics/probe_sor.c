@@ -102,3 +102,100 @@ void sor_probe(const double *const J[10], const double *const A[12], const doubl
     for (int a = 0; a < 3; a++) free(L[a]);
     free(du); free(dv); free(dw); free(wpsi);
 }
+
+/* ---- defect-correction ("delta") form of the same sweep (round 4) -------------------------------------------
+ * d = d0 + delta.  At a psi-update iteration a voxel folds d0 <- d0 + delta (d0 in `d0fmt` precision), builds M
+ * from the factors and stores the RESIDUAL of the window's linear system at d0
+ *     r = L + sum_nb a (d0_nb - d0) - b4 - M d0
+ * (-1 neighbours are already folded in this sweep, +1 neighbours are taken as d0 + delta, which is what they fold
+ * to), and every iteration runs the reference's recurrence (level_solver_3d.py:503-540) on delta with r in place
+ * of b.  M, r, delta may be held in fp32: their rounding is relative to |delta| and |r|, which shrink as the outer
+ * iteration converges, not to |d| and |b|.
+ * fmt: 0 = fp64, 1 = fp32, 2 = packed 42 bit (31 significant bits).  */
+static double rq(double v, int fmt)
+{
+    if (fmt == 1) return (double)(float)v;
+    if (fmt == 2) {
+        unsigned long long b;
+        memcpy(&b, &v, 8);
+        b = (b + (1ull << 21)) & ~((1ull << 22) - 1ull);
+        memcpy(&v, &b, 8);
+        return v;
+    }
+    return v;
+}
+void sor_probe_dc(const double *const A[12], const double *weight, const double *const Lin[3], int Z, int Y, int X,
+                  double ax, double ay, double az, int iters, int lag, double adc, int fmtM, int fmtR, int fmtD,
+                  int fmtD0, int fmtA, int fmtL, double *const dout[3])
+{
+    size_t n = (size_t)Z * Y * X, P = (size_t)Y * X;
+    double *d0[3], *dl[3], *M[6], *r[3], *Ar[12], *L[3];
+    for (int a = 0; a < 3; a++) { d0[a] = calloc(n, 8); dl[a] = calloc(n, 8); r[a] = calloc(n, 8); }
+    for (int a = 0; a < 6; a++) M[a] = calloc(n, 8);
+    for (int a = 0; a < 12; a++) { Ar[a] = malloc(n * 8); for (size_t q = 0; q < n; q++) Ar[a][q] = rq(A[a][q], fmtA); }
+    for (int a = 0; a < 3; a++) { L[a] = malloc(n * 8); for (size_t q = 0; q < n; q++) L[a][q] = rq(Lin[a][q], fmtL); }
+    const double OM = 1.95, diag = 2 * ax + 2 * ay + 2 * az;
+    for (int it = 0; it < iters; it++) {
+        int upd = (it % lag) == 0;
+        for (int k = 0; k < Z; k++) for (int j = 0; j < Y; j++) for (int i = 0; i < X; i++) {
+            size_t c = I3(k, j, i);
+            /* neighbour offsets; a ghost is the voxel itself (old value) */
+            size_t nb[6] = {i > 0 ? c - 1 : c, i < X - 1 ? c + 1 : c, j > 0 ? c - X : c, j < Y - 1 ? c + X : c,
+                            k > 0 ? c - P : c, k < Z - 1 ? c + P : c};
+            const double aw[6] = {ax, ax, ay, ay, az, az};
+            double dn[3][6]; /* delta seen from the six neighbours */
+            double own[3] = {dl[0][c], dl[1][c], dl[2][c]};
+            if (upd) {
+                /* fold: the voxel's full increment becomes d0 (what does not fit d0's format stays in delta) */
+                double full[3], nd0[3];
+                for (int a = 0; a < 3; a++) { full[a] = d0[a][c] + dl[a][c]; nd0[a] = rq(full[a], fmtD0); own[a] = full[a] - nd0[a]; }
+                double val = 0;
+                for (int q = 0; q < 3; q++) {
+                    double rr = Ar[q*4+0][c]*full[0] + Ar[q*4+1][c]*full[1] + Ar[q*4+2][c]*full[2] + Ar[q*4+3][c];
+                    val += rr * rr;
+                }
+                double w = weight[c] * ((adc != 1.0) ? adc * pow(val + 1e-6, adc - 1.0) : 1.0);
+                double m[6] = {0, 0, 0, 0, 0, 0}, b4[3] = {0, 0, 0};
+                static const int pa[6] = {0, 1, 2, 0, 0, 1}, pb[6] = {0, 1, 2, 1, 2, 2};
+                for (int q = 0; q < 3; q++) {
+                    for (int e = 0; e < 6; e++) m[e] += w * Ar[q*4+pa[e]][c] * Ar[q*4+pb[e]][c];
+                    for (int a = 0; a < 3; a++) b4[a] += w * Ar[q*4+a][c] * Ar[q*4+3][c];
+                }
+                /* d0 of the neighbours as they will be (or are) after THEIR fold of this sweep */
+                double lap[3] = {0, 0, 0};
+                for (int q = 0; q < 6; q++) {
+                    int done = (q % 2 == 0) && nb[q] != c; /* -1 neighbours: already folded and relaxed */
+                    for (int a = 0; a < 3; a++) {
+                        double D0, Dl;
+                        if (nb[q] == c) { D0 = nd0[a]; Dl = own[a]; }
+                        else if (done) { D0 = d0[a][nb[q]]; Dl = dl[a][nb[q]]; }
+                        else { double f = d0[a][nb[q]] + dl[a][nb[q]]; D0 = rq(f, fmtD0); Dl = f - D0; }
+                        lap[a] += aw[q] * (D0 - nd0[a]);
+                        dn[a][q] = Dl;
+                    }
+                }
+                double rr[3];
+                rr[0] = (L[0][c] - b4[0]) + lap[0] - (m[0]*nd0[0] + m[3]*nd0[1] + m[4]*nd0[2]);
+                rr[1] = (L[1][c] - b4[1]) + lap[1] - (m[3]*nd0[0] + m[1]*nd0[1] + m[5]*nd0[2]);
+                rr[2] = (L[2][c] - b4[2]) + lap[2] - (m[4]*nd0[0] + m[5]*nd0[1] + m[2]*nd0[2]);
+                for (int e = 0; e < 6; e++) M[e][c] = rq(m[e], fmtM);
+                for (int a = 0; a < 3; a++) { r[a][c] = rq(rr[a], fmtR); d0[a][c] = nd0[a]; }
+            } else {
+                for (int q = 0; q < 6; q++) for (int a = 0; a < 3; a++) dn[a][q] = nb[q] == c ? own[a] : dl[a][nb[q]];
+            }
+            double s[3];
+            for (int a = 0; a < 3; a++) {
+                s[a] = r[a][c];
+                for (int q = 0; q < 6; q++) s[a] += aw[q] * dn[a][q];
+            }
+            double u1 = (1 - OM) * own[0] + OM * (s[0] - M[3][c] * own[1] - M[4][c] * own[2]) / (diag + M[0][c]);
+            double v1 = (1 - OM) * own[1] + OM * (s[1] - M[3][c] * u1 - M[5][c] * own[2]) / (diag + M[1][c]);
+            double w1 = (1 - OM) * own[2] + OM * (s[2] - M[4][c] * u1 - M[5][c] * v1) / (diag + M[2][c]);
+            dl[0][c] = rq(u1, fmtD); dl[1][c] = rq(v1, fmtD); dl[2][c] = rq(w1, fmtD);
+        }
+    }
+    for (int a = 0; a < 3; a++) for (size_t q = 0; q < n; q++) dout[a][q] = d0[a][q] + dl[a][q];
+    for (int a = 0; a < 3; a++) { free(d0[a]); free(dl[a]); free(r[a]); free(L[a]); }
+    for (int a = 0; a < 6; a++) free(M[a]);
+    for (int a = 0; a < 12; a++) free(Ar[a]);
+}
