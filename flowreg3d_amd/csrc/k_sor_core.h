@@ -11,9 +11,19 @@ namespace fr3d {
 
 #define SOR_OMEGA 1.95
 
-template <typename R> __device__ __forceinline__ R fma_(R a, R b, R c);
-template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
-template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
+// The per-voxel arithmetic below also compiles for the host: the window kernel's CPU emulator
+// (tools/emu/sor_win_emu.hip) runs the same code thread by thread.
+#define FR3D_HD __host__ __device__ __forceinline__
+
+template <typename R> FR3D_HD R fma_(R a, R b, R c);
+template <> FR3D_HD float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
+template <> FR3D_HD double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
+
+FR3D_HD double bits_double(unsigned hi, unsigned lo)
+{
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+FR3D_HD unsigned long long double_bits(double x) { return __builtin_bit_cast(unsigned long long, x); }
 
 // ---- storage formats of the solver operands -------------------------------------------------------------
 // float / double: plain arrays.  pk42 (fr3d_params.solver_fp64 == 3): three values share 16 bytes -- the upper 42
@@ -30,8 +40,8 @@ template <> struct Sto<float> {
     static constexpr bool wide = false;  // fp64-grade storage: fp64 pow and fp64 update arithmetic
     __host__ __device__ static constexpr long long elems(long long nvals) { return nvals; }
     static constexpr double bytes_per_value = 4.0;
-    __device__ __forceinline__ static float quant(float x) { return x; }
-    __device__ __forceinline__ static float quant(double x) { return (float)x; }
+    FR3D_HD static float quant(float x) { return x; }
+    FR3D_HD static float quant(double x) { return (float)x; }
 };
 template <> struct Sto<double> {
     using val = double;
@@ -39,7 +49,7 @@ template <> struct Sto<double> {
     static constexpr bool wide = true;
     __host__ __device__ static constexpr long long elems(long long nvals) { return nvals; }
     static constexpr double bytes_per_value = 8.0;
-    __device__ __forceinline__ static double quant(double x) { return x; }
+    FR3D_HD static double quant(double x) { return x; }
 };
 #define PK42_ROUND (1ull << 21)
 #define PK42_MASK (~((1ull << 22) - 1ull))
@@ -50,9 +60,10 @@ template <> struct Sto<pk42> {
     __host__ __device__ static constexpr long long elems(long long nvals) { return nvals / 3 * 4; }
     static constexpr double bytes_per_value = 16.0 / 3.0;
     // round to nearest (ties away from zero) at bit 22 of the fp64 pattern; inf stays inf
-    __device__ __forceinline__ static double quant(double x)
+    FR3D_HD static double quant(double x)
     {
-        return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(x) + PK42_ROUND) & PK42_MASK));
+        const unsigned long long q = (double_bits(x) + PK42_ROUND) & PK42_MASK;
+        return bits_double((unsigned)(q >> 32), (unsigned)q);
     }
 };
 
@@ -63,7 +74,7 @@ struct Rec {
     typename Sto<S>::val v[N];
 };
 template <typename S, int N>
-__device__ __forceinline__ Rec<S, N> ldrec(const S *base, long long voxel)
+FR3D_HD Rec<S, N> ldrec(const S *base, long long voxel)
 {
     if constexpr (std::is_same<S, pk42>::value) {
         static_assert(N % 3 == 0, "pk42 records hold triples");
@@ -72,9 +83,9 @@ __device__ __forceinline__ Rec<S, N> ldrec(const S *base, long long voxel)
 #pragma unroll
         for (int g = 0; g < N / 3; g++) {
             const uint4 q = p[g];
-            r.v[3 * g + 0] = __hiloint2double((int)q.x, (int)((q.w & 0x3FFu) << 22));
-            r.v[3 * g + 1] = __hiloint2double((int)q.y, (int)(((q.w >> 10) & 0x3FFu) << 22));
-            r.v[3 * g + 2] = __hiloint2double((int)q.z, (int)((q.w >> 20) << 22));
+            r.v[3 * g + 0] = bits_double(q.x, (q.w & 0x3FFu) << 22);
+            r.v[3 * g + 1] = bits_double(q.y, ((q.w >> 10) & 0x3FFu) << 22);
+            r.v[3 * g + 2] = bits_double(q.z, (q.w >> 20) << 22);
         }
         return r;
     } else {
@@ -83,15 +94,15 @@ __device__ __forceinline__ Rec<S, N> ldrec(const S *base, long long voxel)
 }
 // values must already be representable (Sto<S>::quant) -- the bits below the format are dropped
 template <typename S, int N>
-__device__ __forceinline__ void strec(S *base, long long voxel, const Rec<S, N> &r)
+FR3D_HD void strec(S *base, long long voxel, const Rec<S, N> &r)
 {
     if constexpr (std::is_same<S, pk42>::value) {
         uint4 *p = reinterpret_cast<uint4 *>(base) + voxel * (N / 3);
 #pragma unroll
         for (int g = 0; g < N / 3; g++) {
-            const unsigned long long b0 = (unsigned long long)__double_as_longlong(r.v[3 * g + 0]);
-            const unsigned long long b1 = (unsigned long long)__double_as_longlong(r.v[3 * g + 1]);
-            const unsigned long long b2 = (unsigned long long)__double_as_longlong(r.v[3 * g + 2]);
+            const unsigned long long b0 = double_bits(r.v[3 * g + 0]);
+            const unsigned long long b1 = double_bits(r.v[3 * g + 1]);
+            const unsigned long long b2 = double_bits(r.v[3 * g + 2]);
             uint4 q;
             q.x = (unsigned)(b0 >> 32);
             q.y = (unsigned)(b1 >> 32);
@@ -106,10 +117,72 @@ __device__ __forceinline__ void strec(S *base, long long voxel, const Rec<S, N> 
 
 // The 3x3 system of one voxel for the current psi window: m[0..5] = M11,M22,M33,M12,M13,M23 with
 // M = sum_c w_c psi_c J_c, m[6..8] = b = L - sum_c w_c psi_c (J14,J24,J34)_c.  psi is frozen between
-// psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration (`upd`)
-// builds them from the square-root factors and, when `store`, writes them; the other iterations
-// stream the 9 stored values -- independent of the channel count.  `e` is the voxel's index inside one
-// volume's arrays, vM/vA/vL the (wave-uniform) element offsets of the volume's slab.
+// psi-update iterations (level_solver_3d.py:356), so M and b are too: an update iteration builds them from the
+// square-root factors (sor_accum_channel per channel, then sor_finish_system) and stores them; the other
+// iterations stream the 9 stored values -- independent of the channel count.
+template <typename R>
+struct SorAcc {
+    R M11 = 0, M22 = 0, M33 = 0, M12 = 0, M13 = 0, M23 = 0, bu = 0, bv = 0, bw = 0;
+};
+// psi_data update (level_solver_3d.py:356-377) of one channel from the increments of iteration t-1, and the channel's
+// share of M and of sum_c w psi (J14,J24,J34).  The quadratic form is evaluated as the sum of three squared residuals
+// of the tensor's square-root factors (see k_tensor.hip) -- algebraically the reference's expression, but stable
+// with fp32 storage.  `wt` = the channel weight of the voxel, `adc` = a_data of the channel.
+template <typename R, typename S>
+FR3D_HD void sor_accum_channel(const Rec<S, 12> &fr, double wt, double adc, R du0, R dv0, R dw0, SorAcc<R> &acc,
+                               [[maybe_unused]] int dbg = 0)
+{
+    const typename Sto<S>::val *f = fr.v;
+    if (adc != 1.0) {
+        const double u_ = (double)du0, v_ = (double)dv0, w_ = (double)dw0;
+        double val = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double r = fma((double)f[4 * k], u_, fma((double)f[4 * k + 1], v_,
+                           fma((double)f[4 * k + 2], w_, (double)f[4 * k + 3])));
+            val = fma(r, r, val);
+        }
+        // fp32 powf (~1 ulp) with fp32 storage: the products below are stored in fp32 anyway, and the fp64
+        // pow's ~600-instruction dependent chain set a ~6 us latency floor on every launch
+#ifdef FR3D_EXPERIMENTS
+        if (dbg & 32) wt *= adc * (val + 1e-6);  // timing experiment: psi without the pow
+        else
+#endif
+        if (Sto<S>::wide) wt *= adc * pow(val + 1e-6, adc - 1.0);  // reference-grade modes
+        else wt *= adc * (double)powf((float)(val + 1e-6), (float)(adc - 1.0));
+    }
+    const R w = (R)Sto<S>::quant(wt);
+    const R x0 = (R)f[0], x1 = (R)f[1], x2 = (R)f[2], x3 = (R)f[3];
+    const R y0 = (R)f[4], y1 = (R)f[5], y2 = (R)f[6], y3 = (R)f[7];
+    const R z0 = (R)f[8], z1 = (R)f[9], z2 = (R)f[10], z3 = (R)f[11];
+    acc.M11 = fma_<R>(w, fma_<R>(z0, z0, fma_<R>(y0, y0, x0 * x0)), acc.M11);
+    acc.M22 = fma_<R>(w, fma_<R>(z1, z1, fma_<R>(y1, y1, x1 * x1)), acc.M22);
+    acc.M33 = fma_<R>(w, fma_<R>(z2, z2, fma_<R>(y2, y2, x2 * x2)), acc.M33);
+    acc.M12 = fma_<R>(w, fma_<R>(z0, z1, fma_<R>(y0, y1, x0 * x1)), acc.M12);
+    acc.M13 = fma_<R>(w, fma_<R>(z0, z2, fma_<R>(y0, y2, x0 * x2)), acc.M13);
+    acc.M23 = fma_<R>(w, fma_<R>(z1, z2, fma_<R>(y1, y2, x1 * x2)), acc.M23);
+    acc.bu = fma_<R>(w, fma_<R>(z0, z3, fma_<R>(y0, y3, x0 * x3)), acc.bu);
+    acc.bv = fma_<R>(w, fma_<R>(z1, z3, fma_<R>(y1, y3, x1 * x3)), acc.bv);
+    acc.bw = fma_<R>(w, fma_<R>(z2, z3, fma_<R>(y2, y3, x2 * x3)), acc.bw);
+}
+// the frozen system in storage precision: M and b = L - sum_c w psi (J14,J24,J34)
+template <typename R, typename S>
+FR3D_HD Rec<S, 9> sor_finish_system(const SorAcc<R> &acc, const Rec<S, 3> &lr)
+{
+    const R b_u = (R)lr.v[0] - acc.bu;
+    const R b_v = (R)lr.v[1] - acc.bv;
+    const R b_w = (R)lr.v[2] - acc.bw;
+    Rec<S, 9> mr;
+    mr.v[0] = Sto<S>::quant(acc.M11); mr.v[1] = Sto<S>::quant(acc.M22); mr.v[2] = Sto<S>::quant(acc.M33);
+    mr.v[3] = Sto<S>::quant(acc.M12); mr.v[4] = Sto<S>::quant(acc.M13); mr.v[5] = Sto<S>::quant(acc.M23);
+    mr.v[6] = Sto<S>::quant(b_u); mr.v[7] = Sto<S>::quant(b_v); mr.v[8] = Sto<S>::quant(b_w);
+    return mr;
+}
+
+// The sweep kernel of k_sor.hip keeps its own monolithic copy of the same arithmetic (splitting it changed the
+// register allocation: 76 -> 81 VGPRs, one wave per SIMD less); tests/test_gpu_sor_window.py holds the two bit-identical.
+// `e` is the voxel's index inside one volume's arrays, vM/vA/vL the (wave-uniform) element offsets of the
+// volume's slab; `upd`: build (and, when `store`, write) the system, else read the stored one.
 template <typename R, typename S, int C>
 __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool store, long long vM, long long vA,
                                            long long vL, long long e, R du0, R dv0, R dw0, R (&m)[9])
@@ -199,7 +272,7 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
 // axis (a ghost neighbour contributes the voxel's own old value, set_boundary_3d :246-259).
 // du uses old dv,dw; dv uses new du, old dw; dw uses new du,dv (level_solver_3d.py:503-540).
 template <typename R>
-__device__ __forceinline__ void sor_relax(const R (&m)[9], double axd, double ayd, double azd, R su_x, R sv_x,
+FR3D_HD void sor_relax(const R (&m)[9], double axd, double ayd, double azd, R su_x, R sv_x,
                                           R sw_x, R su_y, R sv_y, R sw_y, R su_z, R sv_z, R sw_z, R du0, R dv0,
                                           R dw0, R &du1, R &dv1, R &dw1)
 {
@@ -249,7 +322,7 @@ __device__ __forceinline__ void pin(Rec<S, 3> &q, Rec<S, 9> &m, Rec<S, 3> &a, Re
 // sor_relax with the quotients formed unconditionally and selected afterwards (den == 0 never occurs with
 // alpha > 0; same values): no branch for the compiler to sink a neighbour load into
 template <typename R>
-__device__ __forceinline__ void sor_relax_sel(const R (&m)[9], double axd, double ayd, double azd, R su_x, R sv_x,
+FR3D_HD void sor_relax_sel(const R (&m)[9], double axd, double ayd, double azd, R su_x, R sv_x,
                                               R sw_x, R su_y, R sv_y, R sw_y, R su_z, R sv_z, R sw_z, R du0, R dv0,
                                               R dw0, R &du1, R &dv1, R &dw1)
 {
