@@ -37,7 +37,8 @@ class Params(C.Structure):
         ("a_smooth", C.c_double),
         ("a_data", C.c_double * MAX_CHANNELS),
         ("solver_fp64", C.c_int),
-        ("reserved", C.c_int * 7),
+        ("solver_sweep", C.c_int),
+        ("reserved", C.c_int * 6),
     ]
 
 
@@ -201,7 +202,7 @@ def ptr(a):
 
 
 def make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth, a_data, n_channels,
-                solver_fp64=None) -> Params:
+                solver_fp64=None, solver_sweep=0) -> Params:
     p = Params()
     al = np.asarray(alpha, dtype=np.float64).reshape(-1)
     if al.size == 1:
@@ -226,6 +227,7 @@ def make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth,
         p.a_data[c] = float(ad[c])
     # None = FR3D_SOLVER_AUTO: fp32 solver storage for one channel, fp64 for several
     p.solver_fp64 = -1 if solver_fp64 is None else (int(solver_fp64) if solver_fp64 in (0, 1, 2, 3, True, False) else 1)
+    p.solver_sweep = int(solver_sweep)  # 0 = the engine's choice, 1 = plane launches, 2 = window kernel (bit-identical)
     return p
 
 

@@ -95,7 +95,7 @@ def _f32c(a):
 
 def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=20, min_level=0,
                      levels=50, eta=0.8, a_smooth=0.5, a_data=0.45, const_assumption="gc",
-                     uvw=None, weight=None, solver_fp64=None):
+                     uvw=None, weight=None, solver_fp64=None, solver_sweep=0):
     """core/optical_flow_3d.py:319-542 -> (Z,Y,X,3) float64 with components [dx,dy,dz].
 
     fixed/moving are used by the reference only through the fp32 resampler
@@ -103,6 +103,8 @@ def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=2
     ``solver_fp64`` is an extension (fr3d_params.solver_fp64): None = automatic (one channel: fp32 solver storage
     with fp64 update arithmetic up to 2^22 voxels, packed 42-bit storage above; several channels: fp64 storage),
     0 / 1 / 2 / 3 force fp32 / fp64 arithmetic on fp32 storage / fp64 storage / packed 42-bit storage.
+    ``solver_sweep`` (fr3d_params.solver_sweep): 0 = the engine's choice, 1 = one launch per hyperplane step,
+    2 = the window kernel (a psi window per workgroup on chip); the results are bit-identical.
     """
     fixed = np.asarray(fixed)
     moving = np.asarray(moving)
@@ -114,7 +116,7 @@ def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=2
     p, m, n, nc = fixed.shape
     wt = None if is_default_weight(weight, nc) else expand_weight(weight, p, m, n, nc)
     params = _lib.make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth, a_data, nc,
-                              solver_fp64)
+                              solver_fp64, solver_sweep)
     f32, m32 = _f32c(fixed), _f32c(moving)
     u32 = None
     if uvw is not None:

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "fr3d_internal.h"
+#include "k_sor_win_core.h"
 
 namespace fr3d {
 
@@ -224,6 +225,14 @@ struct Engine {
     std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
     std::map<std::tuple<int, int, int, int, int>, SorSched> scheds;  // (Z,Y,X,iterations,lag) of a level (a_smooth != 1)
     std::map<std::tuple<int, int, int, int, int, int>, SorChainSched> chain_scheds;  // (Z,Y,X,iterations,rows,chain): a_smooth == 1
+    std::map<std::tuple<int, int, int, int>, WinSched> win_scheds;  // (Z,Y,iterations,update_lag): window sweep
+    const WinSched &win_sched(const Skew &sk, int iterations, int update_lag)
+    {
+        auto key = std::make_tuple(sk.Z, sk.Y, iterations, update_lag);
+        auto it = win_scheds.find(key);
+        if (it == win_scheds.end()) it = win_scheds.emplace(key, build_win_schedule(sk, iterations, update_lag)).first;
+        return it->second;
+    }
 
     // device tables of the compact skewed layout per level geometry (fr3d_internal.h: Skew::pb / cp)
     struct Compact {
@@ -487,6 +496,8 @@ static void build_ref_pyramid(Engine &e, const std::vector<Level> &lv, const flo
     }
 }
 
+static bool use_window_sweep(const fr3d_params &p, int C, int lz, int ly, int lx);
+
 // Solve `nb` volumes against the same reference pyramid in lock step: every stage before and after
 // the solver runs per volume, the SOR launches advance all nb volumes at once (the launch count per
 // level is fixed by the wavefront schedule, so batching multiplies the work per launch and hides
@@ -605,7 +616,19 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         a.update_lag = p.update_lag;
         if (p.a_smooth == 1.0) {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
-            long long n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.chain_sched(sk, p.iterations));
+            long long n;
+            if (use_window_sweep(p, C, lz, ly, lx) && sor_win_fits(sk)) {
+                // window sweep (k_sor_win.hip): the exports of the slots before the last one, laid out like d
+                WinArgs<S> wa;
+                std::memset(&wa, 0, sizeof(wa));
+                wa.a = a;
+                S *Ebuf = (S *)e.bufs["E_sk" + sn].ensure(e3 * (WIN_WMAX - 1) * nres * sizeof(S));
+                // array q of all volumes together, so that a volume's stride is d's
+                wa.E = Ebuf;
+                wa.strideE = (long long)(e3 * nres);
+                n = launch_sor_win<S>(e.st, wa, p.solver_fp64 != 0, e.win_sched(sk, p.iterations, p.update_lag));
+            } else
+                n = launch_sor<S>(e.st, a, p.solver_fp64 != 0, e.chain_sched(sk, p.iterations));
             // algorithmic traffic of the reference's update: 9C tensor entries + C (w psi) + 3 L + 3 d read, 3 d written,
             // in the solver's storage type: 4 (10C + 9) B with fp32 storage, twice that with fp64 storage, 4/3 of it
             // with packed 42-bit storage
@@ -907,6 +930,21 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
         FR3D_CHECK(nl == nfull, "internal: finest level is not full resolution");
         launch_pack3_f64(e.st, ud[0], ud[1], ud[2], (long long)nfull, flow_out);
     }
+}
+
+// Which kernel runs the a_smooth == 1 sweep of a level (fr3d_params.solver_sweep; env FR3D_SWEEP=planes|window
+// overrides an automatic choice).  Both produce the same bits.
+static bool use_window_sweep(const fr3d_params &p, int C, int lz, int ly, int lx)
+{
+    if (!sor_win_supports(C) || p.iterations <= 0) return false;
+    int sw = p.solver_sweep;
+    if (sw == FR3D_SWEEP_AUTO) {
+        static const char *env = getenv("FR3D_SWEEP");
+        if (env && !strcmp(env, "window")) sw = FR3D_SWEEP_WINDOW;
+        else if (env && !strcmp(env, "planes")) sw = FR3D_SWEEP_PLANES;
+    }
+    (void)lz; (void)ly; (void)lx;
+    return sw == FR3D_SWEEP_WINDOW;
 }
 
 // FR3D_SOLVER_AUTO picks the cheapest mode that keeps the flow within 1e-4 voxels (mean end-point error) of the
@@ -1522,6 +1560,8 @@ static void release_engine(Engine &en)
     en.scheds.clear();
     for (auto &kv : en.chain_scheds) free_sor_chain_schedule(kv.second);
     en.chain_scheds.clear();
+    for (auto &kv : en.win_scheds) free_win_schedule(kv.second);
+    en.win_scheds.clear();
     for (auto &kv : en.gkernels) (void)hipFree(kv.second.first);
     en.gkernels.clear();
     for (auto &kv : en.compacts) {

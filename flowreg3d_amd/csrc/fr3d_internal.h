@@ -374,6 +374,21 @@ void free_sor_schedule(SorSched &s);
 template <typename S>
 long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorChainSched &sched);
 
+// Window form of the same sweep (k_sor_win.hip): one workgroup per (tile of 16 x 16 lines, psi window); launches go
+// by tile diagonals.  `tiles`: device array of all launches back to back.
+struct WinTile;
+template <typename S> struct WinArgs;
+struct WinSched {
+    std::vector<int> first, count;  // per launch
+    WinTile *tiles = nullptr;       // device
+};
+WinSched build_win_schedule(const Skew &sk, int iterations, int update_lag);
+void free_win_schedule(WinSched &ws);
+bool sor_win_supports(int C);
+bool sor_win_fits(const Skew &sk);
+template <typename S>
+long long launch_sor_win(hipStream_t st, const WinArgs<S> &wa, bool fp64, const WinSched &ws);
+
 // K8 median (natural layout)
 void launch_median5(hipStream_t st, const float *in, int Z, int Y, int X, float *out);
 // nf <= 3 fields of one volume in one launch (field f at in + f*fstride): out[f] = median, or out[f] += median

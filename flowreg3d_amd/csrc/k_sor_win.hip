@@ -1,0 +1,110 @@
+// k_sor_win.hip -- the window form of the a_smooth == 1 SOR sweep on gfx950: kernel, device schedule and launcher.
+// The algorithm, the per-thread state and the step function are in k_sor_win_core.h (shared with the CPU emulator
+// tools/emu/sor_win_emu.hip); reference: core/level_solver_3d.py:314-546.
+//
+// One workgroup = 256 threads = one tile of 16 x 16 lines for one psi window, one wave per SIMD: a thread carries the
+// window's whole per-line state in registers (increment history of every slot, the frozen systems on their way from
+// slot to slot, the prefetched operands of the next step: ~300 VGPRs), so the occupancy is one wave per SIMD by
+// design and latency is hidden by the five independent slot updates of a step and by prefetching every global
+// operand one step ahead.  LDS: the slots' outputs of the last two steps (72 KiB with fp64 values), one barrier per step.
+#include <cstdio>
+#include <cstdlib>
+
+#include "fr3d_internal.h"
+#include "k_sor_win_sched.h"
+
+namespace fr3d {
+
+// row-start tables of the level in LDS (dynamic shared memory): pb (S + 2 entries of 8 bytes), then cp (X + Y + 2 ints)
+extern __shared__ long long win_tables[];
+struct WinTabLds {
+    int npb;
+    __device__ __forceinline__ long long pbv(int n) const { return win_tables[n]; }
+    __device__ __forceinline__ int cpv(int n) const { return reinterpret_cast<const int *>(win_tables + npb)[n]; }
+};
+static size_t win_table_bytes(const Skew &sk) { return (size_t)(sk.S + 2) * 8 + (size_t)(sk.X + sk.Y + 2) * 4; }
+
+template <typename R, typename S, int C, int W>
+__global__ void __launch_bounds__(WIN_NT)
+k_sor_win(const WinArgs<S> wa, const WinTile *__restrict__ tiles)
+{
+    using Th = WinThread<R, S, C, W, WinTabLds>;
+    using V = typename Th::V;
+    __shared__ WinLds<V, W> lds;
+    const WinTile tl = tiles[blockIdx.x];
+    const int tid = (int)threadIdx.x;
+    const Skew &sk = wa.a.sk;
+    WinTabLds tb;
+    tb.npb = sk.S + 2;
+    for (int n = tid; n < sk.S + 2; n += WIN_NT) win_tables[n] = sk.pb[n];
+    int *cpl = reinterpret_cast<int *>(win_tables + tb.npb);
+    for (int n = tid; n < sk.X + sk.Y + 2; n += WIN_NT) cpl[n] = sk.cp[n];
+    Th th;
+    th.init(wa, tl, (int)blockIdx.y, tid, 0, 0);
+    int s0, s1;
+    Th::step_range(sk, tl, s0, s1);
+    const WinNoHook hk;
+    __syncthreads();
+    for (int s = s0 - WIN_LEAD; s <= s1; s++) {
+        th.step(wa, tb, s, lds, hk);
+        __syncthreads();
+    }
+}
+
+WinSched build_win_schedule(const Skew &sk, int iterations, int update_lag)
+{
+    WinSched ws;
+    const WinSchedHost h = make_win_schedule(sk.Z, sk.Y, iterations, update_lag, WIN_WMAX);
+    ws.first = h.first;
+    ws.count = h.count;
+    if (!h.tiles.empty()) {
+        FR3D_HIP(hipMalloc((void **)&ws.tiles, h.tiles.size() * sizeof(WinTile)));
+        FR3D_HIP(hipMemcpy(ws.tiles, h.tiles.data(), h.tiles.size() * sizeof(WinTile), hipMemcpyHostToDevice));
+    }
+    return ws;
+}
+
+void free_win_schedule(WinSched &ws)
+{
+    if (ws.tiles) (void)hipFree(ws.tiles);
+    ws.tiles = nullptr;
+}
+
+bool sor_win_supports(int C) { return C >= 1 && C <= 2; }
+// the level's row-start tables must fit beside the exchange buffers in LDS (axes up to ~2000 voxels)
+bool sor_win_fits(const Skew &sk) { return sk.pb != nullptr && win_table_bytes(sk) <= 48 * 1024; }
+
+template <typename R, typename S, int C>
+static void launch_win_step(hipStream_t st, const WinArgs<S> &wa, const WinTile *tiles, int count)
+{
+    const dim3 grid(count, wa.a.nvol > 0 ? wa.a.nvol : 1), block(WIN_NT);
+    hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
+    FR3D_LAUNCH_CHECK();
+}
+
+template <typename S>
+long long launch_sor_win(hipStream_t st, const WinArgs<S> &wa, bool fp64, const WinSched &ws)
+{
+    FR3D_CHECK(sor_win_supports(wa.a.C), "window sweep: 1 or 2 channels");
+    FR3D_CHECK(sor_win_fits(wa.a.sk), "window sweep: level too large for the LDS tables (or pitched layout)");
+    long long launches = 0;
+    for (size_t l = 0; l < ws.first.size(); l++) {
+        if (ws.count[l] <= 0) continue;
+        const WinTile *tiles = ws.tiles + ws.first[l];
+        const bool r64 = Sto<S>::wide || fp64;
+        if (wa.a.C == 1) {
+            if (r64) launch_win_step<double, S, 1>(st, wa, tiles, ws.count[l]);
+            else if constexpr (!Sto<S>::wide) launch_win_step<float, S, 1>(st, wa, tiles, ws.count[l]);
+        } else {
+            if (r64) launch_win_step<double, S, 2>(st, wa, tiles, ws.count[l]);
+            else if constexpr (!Sto<S>::wide) launch_win_step<float, S, 2>(st, wa, tiles, ws.count[l]);
+        }
+        launches++;
+    }
+    return launches;
+}
+template long long launch_sor_win<float>(hipStream_t, const WinArgs<float> &, bool, const WinSched &);
+template long long launch_sor_win<double>(hipStream_t, const WinArgs<double> &, bool, const WinSched &);
+template long long launch_sor_win<pk42>(hipStream_t, const WinArgs<pk42> &, bool, const WinSched &);
+
+}  // namespace fr3d

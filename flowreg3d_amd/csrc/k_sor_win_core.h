@@ -55,14 +55,35 @@ struct alignas(16) WinTile {
 template <typename S>
 struct WinArgs {
     SorArgsT<S> a;           // M (records of 9), A, weight, L, d (in place), geometry, constants, batch strides
-    S *E[WIN_WMAX - 1];      // exports of slots 0 .. W-2, records of 3, laid out and strided like d
+    S *E;                    // exports of slots 0 .. W-2, records of 3: array q starts at E + q * strideE, laid out and
+    long long strideE;       // strided (per volume) like d
 };
 
-// LDS image of one workgroup: outputs of step s-1 (and s) of slot -1 (the loader) .. W-1, structure of arrays
+// LDS image of one workgroup: outputs of step s-1 (and s) of slot -1 (the loader) .. W-1, structure of arrays; and
+// each thread's own "import" records (neighbour values that come from another tile): a thread that needs one reads its
+// import slot INSTEAD of the neighbouring thread's output -- one select on the LDS address, not one per value.
+enum { WIN_IMP_ZM = 0, WIN_IMP_YM = 1, WIN_IMP_YP_SW = 2, WIN_IMP_ZP_SW = 3, WIN_IMP_ZP_TOP = 4, WIN_IMP_YP_TOP = 5, WIN_IMP_N = 6 };
 template <typename V, int W>
 struct WinLds {
     V O[2][W + 1][3][WIN_NT];
+    V imp[WIN_IMP_N][3][WIN_NT];
 };
+
+// Row-start tables of the compact skewed layout (Skew::pb / cp) as the kernel sees them: the device keeps copies in
+// LDS (a dependent GLOBAL load in front of every prefetch address made each step a chain of memory round trips), the
+// emulator reads the host vectors.
+struct WinTabPtr {
+    const long long *pb;
+    const int *cp;
+    FR3D_HD long long pbv(int n) const { return pb[n]; }
+    FR3D_HD int cpv(int n) const { return cp[n]; }
+};
+template <typename Tab>
+FR3D_HD long long win_index(const Tab &tb, int X, int k, int j, int i)
+{
+    const int r = i + j, s = r + k;
+    return tb.pbv(s + 1) - (long long)tb.cpv(r + 1) + (j - sk_jm(X, r));
+}
 
 // Memory hook: the device build reads and writes plainly; the emulator's hook checks that a value read was written
 // by the expected window (and not by a workgroup of the same launch).
@@ -72,7 +93,15 @@ struct WinNoHook {
 };
 enum { WIN_ARR_D = 0, WIN_ARR_M = 1, WIN_ARR_E0 = 2 };  // array ids of the hook (E[q] = WIN_ARR_E0 + q)
 
-template <typename R, typename S, int C, int W, typename Hook = WinNoHook>
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WIN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WIN_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)  // wave-uniform: a branch, not a per-lane select
+#else
+#define WIN_SCHED_FENCE() ((void)0)
+#define WIN_ANY(c) (c)
+#endif
+
+template <typename R, typename S, int C, int W, typename Tab = WinTabPtr, typename Hook = WinNoHook>
 struct WinThread {
     using V = typename Sto<S>::val;
     static_assert(W >= 1 && W <= WIN_WMAX, "window slots");
@@ -80,24 +109,24 @@ struct WinThread {
 
     // ---- constant per thread ----
     int a, b, tid;
-    int K, J, t0, nsl;
+    int K, J, nsl;
     bool build, storeM;
     int qa, qb;  // the slot in which this thread is the bottom of the range in a / in b (>= W: never)
     int Z, Y, X;
     long long vD, vM, vA, vL;  // volume offsets (storage elements)
+    int win, win_build;        // window of this workgroup / of the psi update its system belongs to (hook versions)
 
     // ---- state ----
-    V Om1[W + 1][3], Om2[W + 1][3];  // outputs of slot q-1 .. (index q+1) in steps s-1 and s-2
-    V H[W][9];                       // H[q]: system record slot q needs in THIS step parity ... see hand-off below
-    V H2[W][9];                      // the other parity
-    // prefetched for the next use (same program point, one step later)
-    Rec<S, 3> Lnext;                 // loader: d_in of the slot-0 line at voxel i0 + 3 of the step it is issued in
+    V Om1[W + 1][3], Om2[W + 1][3];  // slot q's line in slot q-1 (the loader for q = 0), steps s-1 and s-2: its i+1 neighbour, its own old value
+    V H1[W][9], H2[W][9];            // frozen systems on their way to slot q: H2[q] is read in this step, H1[q] in the next
+    // prefetched for the next step
+    Rec<S, 3> Lnext;                 // loader: d of the slot-0 line, two voxels ahead of slot 0
     Rec<S, 12> fr[C];
     double wt[C];
-    Rec<S, 3> lr;
-    Rec<S, 9> mx;
+    Rec<S, 3> lr;                    // build: Laplacian terms
+    Rec<S, 9> mx;                    // no build: the stored system
     Rec<S, 3> NBa, NBb;              // -1 neighbour across the tile edge (slot qa / qb)
-    Rec<S, 3> SWa0, SWa1, SWb0, SWb1;  // taken-over line: own old value (voxel i), its i+1 neighbour
+    Rec<S, 3> SWa, SWb;              // taken-over line: the i+1 neighbour of the next step's voxel (becomes its own old value a step later)
     Rec<S, 3> SXa, SXb;              // taken-over line: +1 neighbour in the other direction (same exported row)
     Rec<S, 9> SMa, SMb;              // taken-over line: frozen system
     Rec<S, 3> TOPa, TOPb;            // slot 0, top row / column: +1 neighbour of the previous window (d)
@@ -107,6 +136,10 @@ struct WinThread {
     FR3D_HD int kq(int q) const { return kline(K, a, q); }
     FR3D_HD int jq(int q) const { return jline(J, b, q); }
     FR3D_HD bool line_ok(int k, int j) const { return k >= 0 && k < Z && j >= 0 && j < Y; }
+    FR3D_HD static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+    // value select: `c ? x : y` on two members is an LVALUE conditional, which reaches the optimiser as a select of two
+    // ADDRESSES inside the thread object and keeps the whole object in scratch memory (no scalar replacement)
+    FR3D_HD static V sel(bool c, V x, V y) { return c ? x : y; }
 
     template <int N>
     FR3D_HD static void zero(Rec<S, N> &r)
@@ -115,34 +148,13 @@ struct WinThread {
         for (int n = 0; n < N; n++) r.v[n] = 0;
     }
 
-    // record loads / stores at voxel (k,j,i) of one volume's slab; `arr`: hook id
-    template <int N>
-    FR3D_HD Rec<S, N> ld(const S *base, long long vol_off, const Skew &sk, int k, int j, int i, int arr, int want,
-                         const Hook &hk) const
-    {
-        const long long e = sk_index(sk, k, j, i);
-        hk.rd(arr, e, want);
-        return ldrec<S, N>(base + vol_off, e);
-    }
-    template <int N>
-    FR3D_HD void st(S *base, long long vol_off, const Skew &sk, int k, int j, int i, const Rec<S, N> &r, int arr,
-                    int ver, const Hook &hk) const
-    {
-        const long long e = sk_index(sk, k, j, i);
-        hk.wr(arr, e, ver);
-        strec<S, N>(base + vol_off, e, r);
-    }
-
-    // window index of this workgroup's window / of the psi update its system belongs to (hook versions)
-    int win, win_build;
-
     FR3D_HD void init(const WinArgs<S> &wa, const WinTile &tl, int vol, int tid_, int win_, int win_build_)
     {
         const SorArgsT<S> &A_ = wa.a;
         tid = tid_;
         a = tid / WIN_BJ;
         b = tid % WIN_BJ;
-        K = tl.K; J = tl.J; t0 = tl.t0;
+        K = tl.K; J = tl.J;
         nsl = tl.info & 0xff;
         build = (tl.info >> 8) & 1;
         storeM = (tl.info >> 9) & 1;
@@ -158,14 +170,15 @@ struct WinThread {
 #pragma unroll
         for (int q = 0; q < W; q++)
 #pragma unroll
-            for (int n = 0; n < 9; n++) H[q][n] = H2[q][n] = 0;
-        zero(Lnext); zero(lr); zero(mx); zero(NBa); zero(NBb); zero(SWa0); zero(SWa1); zero(SWb0); zero(SWb1);
+            for (int n = 0; n < 9; n++) H1[q][n] = H2[q][n] = 0;
+        zero(Lnext); zero(lr); zero(mx); zero(NBa); zero(NBb); zero(SWa); zero(SWb);
         zero(SXa); zero(SXb); zero(SMa); zero(SMb); zero(TOPa); zero(TOPb);
 #pragma unroll
         for (int c = 0; c < C; c++) { zero(fr[c]); wt[c] = 0; }
     }
 
-    // first step in which any slot of this tile has a voxel, and the last one
+    // first step in which any slot of this tile has a voxel, and the last one; the kernel starts WIN_LEAD steps
+    // earlier, with every slot still idle, so that the prefetch pipelines fill through the ordinary step code
     FR3D_HD static void step_range(const Skew &sk, const WinTile &tl, int &s_first, int &s_last)
     {
         const int nsl = tl.info & 0xff;
@@ -177,19 +190,23 @@ struct WinThread {
         s_last = khi + jhi + (sk.X - 1) + 2 * (nsl - 1);
     }
 
-    // ---- the prefetches: each is (re)issued right after its value for the current step has been consumed, for the
-    // voxel of the NEXT step; prime() issues them all for the first step ----
-    FR3D_HD void load_loader(const WinArgs<S> &wa, int s_next, const Hook &hk)
+    // ---- the prefetches of step s_next, issued one step ahead ----
+    // Every thread's own-line operands: unconditional loads at clamped coordinates (a voxel outside the volume reads a
+    // valid record that nobody uses), so the compiler can count the loads in flight instead of draining them at a join.
+    FR3D_HD void load_loader(const WinArgs<S> &wa, const Tab &tb, int s_next, const Hook &hk)
     {
-        // O_{-1}(s) = d_in of the slot-0 line at voxel s + 2 - k - j
+        // O_{-1}(s) = d of the slot-0 line at voxel s + 2 - k - j
         const int k = kq(0), j = jq(0), i = s_next + 2 - k - j;
-        if (line_ok(k, j) && i >= 0 && i < X) Lnext = ld<3>(wa.a.d, vD, wa.a.sk, k, j, i, WIN_ARR_D, win - 1, hk);
+        const bool ok = line_ok(k, j) && i >= 0 && i < X;
+        const long long e = win_index(tb, X, clampi(k, 0, Z - 1), clampi(j, 0, Y - 1), clampi(i, 0, X - 1));
+        if (ok) hk.rd(WIN_ARR_D, e, win - 1);
+        Lnext = ldrec<S, 3>(wa.a.d + vD, e);
     }
-    FR3D_HD void load_slot0(const WinArgs<S> &wa, int s_next, const Hook &hk)
+    FR3D_HD void load_slot0(const WinArgs<S> &wa, const Tab &tb, int s_next, const Hook &hk)
     {
         const int k = kq(0), j = jq(0), i = s_next - k - j;
-        if (!(line_ok(k, j) && i >= 0 && i < X)) return;
-        const long long e = sk_index(wa.a.sk, k, j, i);
+        const bool ok = line_ok(k, j) && i >= 0 && i < X;
+        const long long e = win_index(tb, X, clampi(k, 0, Z - 1), clampi(j, 0, Y - 1), clampi(i, 0, X - 1));
         if (build) {
 #pragma unroll
             for (int c = 0; c < C; c++) {
@@ -198,199 +215,233 @@ struct WinThread {
             }
             lr = ldrec<S, 3>(wa.a.L + vL, e);
         } else {
-            hk.rd(WIN_ARR_M, e, win_build);
+            if (ok) hk.rd(WIN_ARR_M, e, win_build);
             mx = ldrec<S, 9>(wa.a.M + vM, e);
         }
-        // slot 0, top row / column: the +1 neighbour belongs to the tile above; its value of the previous window is in d
-        if (a == WIN_BK - 1 && k + 1 < Z) TOPa = ld<3>(wa.a.d, vD, wa.a.sk, k + 1, j, i, WIN_ARR_D, win - 1, hk);
-        if (b == WIN_BJ - 1 && j + 1 < Y) TOPb = ld<3>(wa.a.d, vD, wa.a.sk, k, j + 1, i, WIN_ARR_D, win - 1, hk);
     }
-    // the slot-q imports of a thread that is the bottom of the range in a (dir 0) or in b (dir 1)
-    FR3D_HD void load_special(const WinArgs<S> &wa, int q, int dir, int s_next, const Hook &hk)
+    // slot 0, top row / column: the +1 neighbour belongs to the tile above; its value of the previous window is in d
+    FR3D_HD void load_top(const WinArgs<S> &wa, const Tab &tb, int s_next, const Hook &hk)
+    {
+        const int k = kq(0), j = jq(0), i = s_next - k - j;
+        if (!(line_ok(k, j) && i >= 0 && i < X)) return;
+        if (a == WIN_BK - 1 && k + 1 < Z) {
+            const long long en = win_index(tb, X, k + 1, j, i);
+            hk.rd(WIN_ARR_D, en, win - 1);
+            TOPa = ldrec<S, 3>(wa.a.d + vD, en);
+        }
+        if (b == WIN_BJ - 1 && j + 1 < Y) {
+            const long long en = win_index(tb, X, k, j + 1, i);
+            hk.rd(WIN_ARR_D, en, win - 1);
+            TOPb = ldrec<S, 3>(wa.a.d + vD, en);
+        }
+    }
+    // the imports of a thread that is the bottom of the range in a (dir 0) or in b (dir 1), in its slot q = qa / qb
+    template <int dir>
+    FR3D_HD void load_special(const WinArgs<S> &wa, const Tab &tb, int q, int s_next, const Hook &hk)
     {
         if (q >= nsl) return;
         const int k = kq(q), j = jq(q), i = s_next - 2 * q - k - j;
         if (!line_ok(k, j)) return;
-        const Skew &sk = wa.a.sk;
         const bool last = q == nsl - 1;
+        const bool in = i >= 0 && i < X;
         // -1 neighbour across the edge: this window's slot-q value of the line below (exported, or final in d)
         const int kn = dir == 0 ? k - 1 : k, jn = dir == 0 ? j : j - 1;
-        if (i >= 0 && i < X && kn >= 0 && jn >= 0) {
-            const S *src = last ? wa.a.d : wa.E[q];
-            const Rec<S, 3> r = ld<3>(src, vD, sk, kn, jn, i, last ? WIN_ARR_D : WIN_ARR_E0 + q, win, hk);
-            if (dir == 0) NBa = r; else NBb = r;
+        if (in && kn >= 0 && jn >= 0) {
+            const long long e = win_index(tb, X, kn, jn, i);
+            hk.rd(last ? WIN_ARR_D : WIN_ARR_E0 + q, e, win);
+            const S *src = last ? wa.a.d + vD : wa.E + (long long)q * wa.strideE + vD;
+            (dir == 0 ? NBa : NBb) = ldrec<S, 3>(src, e);
         }
         if (q == 0) return;
-        // the line is taken over from the tile below: its slot q-1 values come from that tile's exports.
+        const S *Eprev = wa.E + (long long)(q - 1) * wa.strideE + vD;
+        // the line is taken over from the tile below: its slot q-1 values come from that tile's exports
         // (both directions change in the same slot: direction a loads the line's own values)
-        const bool own = dir == 0 || qa != qb;
-        if (own) {
-            // own old value of the NEXT step's voxel is this step's i+1 neighbour: load voxel i + 1 only
+        if (dir == 0 || qa != qb) {
+            // voxel i + 1: the i+1 neighbour of step s_next, and one step later the voxel's own old value
             if (i + 1 >= 0 && i + 1 < X) {
-                const Rec<S, 3> r = ld<3>(wa.E[q - 1], vD, sk, k, j, i + 1, WIN_ARR_E0 + q - 1, win, hk);
-                if (dir == 0) SWa1 = r; else SWb1 = r;
+                const long long e = win_index(tb, X, k, j, i + 1);
+                hk.rd(WIN_ARR_E0 + q - 1, e, win);
+                (dir == 0 ? SWa : SWb) = ldrec<S, 3>(Eprev, e);
             }
-            if (i >= 0 && i < X) {
-                const long long e = sk_index(sk, k, j, i);
+            if (in) {
+                const long long e = win_index(tb, X, k, j, i);
                 hk.rd(WIN_ARR_M, e, win_build);
-                const Rec<S, 9> r = ldrec<S, 9>(wa.a.M + vM, e);
-                if (dir == 0) SMa = r; else SMb = r;
+                (dir == 0 ? SMa : SMb) = ldrec<S, 9>(wa.a.M + vM, e);
             }
         }
         // the +1 neighbour in the OTHER direction lies on the same exported row / column
         const int kx = dir == 0 ? k : k + 1, jx = dir == 0 ? j + 1 : j;
-        if (i >= 0 && i < X && kx < Z && jx < Y) {
-            const Rec<S, 3> r = ld<3>(wa.E[q - 1], vD, sk, kx, jx, i, WIN_ARR_E0 + q - 1, win, hk);
-            if (dir == 0) SXa = r; else SXb = r;
+        if (in && kx < Z && jx < Y) {
+            const long long e = win_index(tb, X, kx, jx, i);
+            hk.rd(WIN_ARR_E0 + q - 1, e, win);
+            (dir == 0 ? SXa : SXb) = ldrec<S, 3>(Eprev, e);
         }
     }
 
-    FR3D_HD void prime(const WinArgs<S> &wa, int s_first, const Hook &hk)
-    {
-        // loader pipeline: O_{-1}(s_first - 2), O_{-1}(s_first - 1) and the value published in step s_first
-        load_loader(wa, s_first - 2, hk);
-#pragma unroll
-        for (int c = 0; c < 3; c++) Om2[0][c] = Lnext.v[c];
-        load_loader(wa, s_first - 1, hk);
-#pragma unroll
-        for (int c = 0; c < 3; c++) Om1[0][c] = Lnext.v[c];
-        load_loader(wa, s_first, hk);
-        load_slot0(wa, s_first, hk);
-        // taken-over lines: SW?1 of step s - 1 becomes SW?0 of step s
-        if (qa >= 1 && qa < W) { load_special(wa, qa, 0, s_first - 1, hk); SWa0 = SWa1; }
-        if (qb >= 1 && qb < W) { load_special(wa, qb, 1, s_first - 1, hk); SWb0 = SWb1; }
-        if (qa < W) load_special(wa, qa, 0, s_first, hk);
-        if (qb < W) load_special(wa, qb, 1, s_first, hk);
-    }
-
-    // ---- one step ----
-    // `prev` / `cur`: LDS images of steps s-1 and s.  Slots are processed from the last to the first so that the
-    // system record of slot q can be handed to slot q+1 (for step s+2) once slot q+1 has used its own.
+    // ---- one slot of one step ----
+    // The line's own history (Om1/Om2) and its system record (H2) already hold the imported values where the line was
+    // taken over (end_of_step), so the slot body has no special cases except WHERE the four cross-line neighbours are
+    // read from, and the ghosts at the volume's faces (a wave-uniform branch: most waves have none).
     template <int q>
-    FR3D_HD void slot(const WinArgs<S> &wa, int s, const V (*prev)[3][WIN_NT], V (&Onew)[W + 1][3], V (&Hp)[W][9],
-                      const Hook &hk)
+    FR3D_HD void slot(const WinArgs<S> &wa, const Tab &tb, int s, const WinLds<V, W> &lds, int pp, V (&Onew)[W + 1][3],
+                      V (&Hnew)[W][9], const Hook &hk)
     {
         const SorArgsT<S> &A_ = wa.a;
         const int k = kq(q), j = jq(q), i = s - 2 * q - k - j;
         const bool spa = q == qa, spb = q == qb;
         const bool active = q < nsl && line_ok(k, j) && i >= 0 && i < X;
-        V sys[9];
-        if (active) {
-            V own[3], xp[3], xm[3], yp[3], ym[3], zp[3], zm[3];
-            const bool swa = q >= 1 && spa, swb = q >= 1 && spb && !spa;
-            // the line's own history: registers, or the import of the slot in which the line was taken over
+        V own[3], xp[3], xm[3], yp[3], ym[3], zp[3], zm[3], sys[9];
+        const int t_am = ((a + WIN_BK - 1) % WIN_BK) * WIN_BJ + b, t_ap = ((a + 1) % WIN_BK) * WIN_BJ + b;
+        const int t_bm = a * WIN_BJ + (b + WIN_BJ - 1) % WIN_BJ, t_bp = a * WIN_BJ + (b + 1) % WIN_BJ;
+        // -1 neighbours: this slot, step s-1;  +1 neighbours: slot q-1 (q = 0: the loader), step s-1; or the import slot
+        const V *pzm = spa ? &lds.imp[WIN_IMP_ZM][0][tid] : &lds.O[pp][q + 1][0][t_am];
+        const V *pym = spb ? &lds.imp[WIN_IMP_YM][0][tid] : &lds.O[pp][q + 1][0][t_bm];
+        const V *pzp, *pyp;
+        if (q == 0) {
+            pzp = a == WIN_BK - 1 ? &lds.imp[WIN_IMP_ZP_TOP][0][tid] : &lds.O[pp][q][0][t_ap];
+            pyp = b == WIN_BJ - 1 ? &lds.imp[WIN_IMP_YP_TOP][0][tid] : &lds.O[pp][q][0][t_bp];
+        } else {
+            pzp = spb ? &lds.imp[WIN_IMP_ZP_SW][0][tid] : &lds.O[pp][q][0][t_ap];
+            pyp = spa ? &lds.imp[WIN_IMP_YP_SW][0][tid] : &lds.O[pp][q][0][t_bp];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            own[c] = Om2[q][c];
+            xp[c] = Om1[q][c];
+            // i-1 neighbour: this thread's own output of step s-1.  From LDS, not from Om1[q + 1]: where slot q+1
+            // takes another line over, that entry holds the other line's import
+            xm[c] = lds.O[pp][q + 1][c][tid];
+            zm[c] = pzm[c * WIN_NT]; ym[c] = pym[c * WIN_NT];
+            zp[c] = pzp[c * WIN_NT]; yp[c] = pyp[c * WIN_NT];
+        }
+        // Neumann ghosts (set_boundary_3d :246-259): a missing neighbour is the voxel's own old value
+        const bool ghost = i <= 0 || i >= X - 1 || j == 0 || j == Y - 1 || k == 0 || k == Z - 1;
+        if (WIN_ANY(ghost)) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                own[c] = swa ? SWa0.v[c] : (swb ? SWb0.v[c] : Om2[q][c]);
-                const V xpv = swa ? SWa1.v[c] : (swb ? SWb1.v[c] : Om1[q][c]);
-                xp[c] = i < X - 1 ? xpv : own[c];
-                xm[c] = i > 0 ? Om1[q + 1][c] : own[c];
+                xp[c] = sel(i < X - 1, xp[c], own[c]);
+                xm[c] = sel(i > 0, xm[c], own[c]);
+                zm[c] = sel(k > 0, zm[c], own[c]);
+                ym[c] = sel(j > 0, ym[c], own[c]);
+                zp[c] = sel(k < Z - 1, zp[c], own[c]);
+                yp[c] = sel(j < Y - 1, yp[c], own[c]);
             }
-            const int t_am = ((a + WIN_BK - 1) % WIN_BK) * WIN_BJ + b, t_ap = ((a + 1) % WIN_BK) * WIN_BJ + b;
-            const int t_bm = a * WIN_BJ + (b + WIN_BJ - 1) % WIN_BJ, t_bp = a * WIN_BJ + (b + 1) % WIN_BJ;
+        }
+        // the frozen system
+        if (q == 0) {
+            Rec<S, 9> mr;
+            if (build) {
+                SorAcc<R> acc;
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                // -1 neighbours: this slot, step s-1
-                zm[c] = k > 0 ? (spa ? NBa.v[c] : prev[q + 1][c][t_am]) : own[c];
-                ym[c] = j > 0 ? (spb ? NBb.v[c] : prev[q + 1][c][t_bm]) : own[c];
-                // +1 neighbours: slot q-1 (q = 0: the loader), step s-1
-                V zpv, ypv;
-                if (q == 0) {
-                    zpv = a == WIN_BK - 1 ? TOPa.v[c] : prev[q][c][t_ap];
-                    ypv = b == WIN_BJ - 1 ? TOPb.v[c] : prev[q][c][t_bp];
-                } else {
-                    zpv = spb ? SXb.v[c] : prev[q][c][t_ap];
-                    ypv = spa ? SXa.v[c] : prev[q][c][t_bp];
+                for (int c = 0; c < C; c++)
+                    sor_accum_channel<R, S>(fr[c], wt[c], A_.a_data[c], (R)own[0], (R)own[1], (R)own[2], acc);
+                mr = sor_finish_system<R, S>(acc, lr);
+                // lines that another tile takes over later need the record in memory
+                if (active && (storeM || a >= WIN_BK - W + 1 || b >= WIN_BJ - W + 1)) {
+                    const long long e = win_index(tb, X, k, j, i);
+                    hk.wr(WIN_ARR_M, e, win);
+                    strec<S, 9>(A_.M + vM, e, mr);
                 }
-                zp[c] = k < Z - 1 ? zpv : own[c];
-                yp[c] = j < Y - 1 ? ypv : own[c];
-            }
-            // the frozen system
-            if (q == 0) {
-                Rec<S, 9> mr;
-                if (build) {
-                    SorAcc<R> acc;
-#pragma unroll
-                    for (int c = 0; c < C; c++)
-                        sor_accum_channel<R, S>(fr[c], wt[c], A_.a_data[c], (R)own[0], (R)own[1], (R)own[2], acc);
-                    mr = sor_finish_system<R, S>(acc, lr);
-                    // lines that another tile takes over later need the record in memory
-                    if (storeM || a >= WIN_BK - W + 1 || b >= WIN_BJ - W + 1) st<9>(A_.M, vM, A_.sk, k, j, i, mr, WIN_ARR_M, win, hk);
-                } else {
-                    mr = mx;
-                }
-#pragma unroll
-                for (int n = 0; n < 9; n++) sys[n] = mr.v[n];
             } else {
-#pragma unroll
-                for (int n = 0; n < 9; n++) sys[n] = swa ? SMa.v[n] : (swb ? SMb.v[n] : Hp[q][n]);
+                mr = mx;
             }
-            R m[9];
 #pragma unroll
-            for (int n = 0; n < 9; n++) m[n] = (R)sys[n];
-            R du1, dv1, dw1;
-            sor_relax<R>(m, A_.ax, A_.ay, A_.az, (R)xm[0] + (R)xp[0], (R)xm[1] + (R)xp[1], (R)xm[2] + (R)xp[2],
-                         (R)ym[0] + (R)yp[0], (R)ym[1] + (R)yp[1], (R)ym[2] + (R)yp[2], (R)zm[0] + (R)zp[0],
-                         (R)zm[1] + (R)zp[1], (R)zm[2] + (R)zp[2], (R)own[0], (R)own[1], (R)own[2], du1, dv1, dw1);
-            Rec<S, 3> out;
-            out.v[0] = Sto<S>::quant(du1);
-            out.v[1] = Sto<S>::quant(dv1);
-            out.v[2] = Sto<S>::quant(dw1);
+            for (int n = 0; n < 9; n++) sys[n] = mr.v[n];
+            // everything slot 0 reads from memory has been used: request the next step's
+            load_slot0(wa, tb, s + 1, hk);
+        } else {
 #pragma unroll
-            for (int c = 0; c < 3; c++) Onew[q + 1][c] = out.v[c];
-            if (q == nsl - 1) st<3>(A_.d, vD, A_.sk, k, j, i, out, WIN_ARR_D, win, hk);
-            else if constexpr (q < W - 1) {
-                if (a == WIN_BK - 1 - q || b == WIN_BJ - 1 - q) st<3>(wa.E[q], vD, A_.sk, k, j, i, out, WIN_ARR_E0 + q, win, hk);
+            for (int n = 0; n < 9; n++) sys[n] = H2[q][n];
+        }
+        R m[9];
+#pragma unroll
+        for (int n = 0; n < 9; n++) m[n] = (R)sys[n];
+        R du1, dv1, dw1;
+        sor_relax<R>(m, A_.ax, A_.ay, A_.az, (R)xm[0] + (R)xp[0], (R)xm[1] + (R)xp[1], (R)xm[2] + (R)xp[2],
+                     (R)ym[0] + (R)yp[0], (R)ym[1] + (R)yp[1], (R)ym[2] + (R)yp[2], (R)zm[0] + (R)zp[0],
+                     (R)zm[1] + (R)zp[1], (R)zm[2] + (R)zp[2], (R)own[0], (R)own[1], (R)own[2], du1, dv1, dw1);
+        Rec<S, 3> out;
+        out.v[0] = Sto<S>::quant(du1);
+        out.v[1] = Sto<S>::quant(dv1);
+        out.v[2] = Sto<S>::quant(dw1);
+#pragma unroll
+        for (int c = 0; c < 3; c++) Onew[q + 1][c] = out.v[c];
+        if (active) {
+            const bool fin = q == nsl - 1;
+            bool exp_ = false;
+            if constexpr (q < W - 1) exp_ = a == WIN_BK - 1 - q || b == WIN_BJ - 1 - q;
+            if (fin || exp_) {
+                const long long e = win_index(tb, X, k, j, i);
+                hk.wr(fin ? WIN_ARR_D : WIN_ARR_E0 + q, e, win);
+                S *dst = fin ? A_.d + vD : wa.E + (long long)q * wa.strideE + vD;
+                strec<S, 3>(dst, e, out);
             }
         }
-        // hand the record on: slot q+1 needs it in step s+2 (same parity); slot q+1 has already run in this step
-        if (q + 1 < W) {
+        // the record travels on: slot q+1 reads it two steps from now
+        if constexpr (q + 1 < W) {
 #pragma unroll
-            for (int n = 0; n < 9; n++) Hp[q + 1][n] = active ? sys[n] : Hp[q + 1][n];
+            for (int n = 0; n < 9; n++) Hnew[q + 1][n] = sys[n];
         }
-        // refill this slot's prefetch registers for step s+1
-        if (q == 0) load_slot0(wa, s + 1, hk);
-        if (spa || spb) {
-            if (q >= 1) {
-                if (spa) SWa0 = SWa1;
-                if (spb) SWb0 = SWb1;
-            }
-            if (spa) load_special(wa, q, 0, s + 1, hk);
-            if (spb) load_special(wa, q, 1, s + 1, hk);
-        }
+        WIN_SCHED_FENCE();
     }
 
     template <int q>
-    FR3D_HD void slots_down(const WinArgs<S> &wa, int s, const V (*prev)[3][WIN_NT], V (&Onew)[W + 1][3], V (&Hp)[W][9],
-                            const Hook &hk)
+    FR3D_HD void slots_down(const WinArgs<S> &wa, const Tab &tb, int s, const WinLds<V, W> &lds, int pp,
+                            V (&Onew)[W + 1][3], V (&Hnew)[W][9], const Hook &hk)
     {
-        slot<q>(wa, s, prev, Onew, Hp, hk);
-        if constexpr (q > 0) slots_down<q - 1>(wa, s, prev, Onew, Hp, hk);
+        slot<q>(wa, tb, s, lds, pp, Onew, Hnew, hk);
+        if constexpr (q >= 1) slots_down<q - 1>(wa, tb, s, lds, pp, Onew, Hnew, hk);
     }
 
-    // step s: read `prev`, compute every slot, publish the outputs in `cur`; the caller puts a barrier behind it
-    FR3D_HD void step(const WinArgs<S> &wa, int s, const V (*prev)[3][WIN_NT], V (*cur)[3][WIN_NT], const Hook &hk)
+    // step s: the imports of step s+1 go out first (they have the whole step to arrive), then every slot, last to
+    // first, reading the LDS image of step s-1; at the end the state moves on one step -- where a line is taken over
+    // from another tile (slot qa / qb of this thread) its history and its system are REPLACED by the imports there, so
+    // the slots never look at them -- and the outputs and neighbour imports are published in LDS.  The caller puts a
+    // barrier behind it.
+    FR3D_HD void step(const WinArgs<S> &wa, const Tab &tb, int s, WinLds<V, W> &lds, const Hook &hk)
     {
-        V Onew[W + 1][3];
+        if (qa < W) load_special<0>(wa, tb, qa, s + 1, hk);
+        if (qb < W) load_special<1>(wa, tb, qb, s + 1, hk);
+        load_top(wa, tb, s + 1, hk);
+        V Onew[W + 1][3], Hnew[W][9];
 #pragma unroll
-        for (int q = 0; q <= W; q++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) Onew[q][c] = 0;
-        // the loader's output of this step was requested one step ago
-#pragma unroll
-        for (int c = 0; c < 3; c++) Onew[0][c] = Lnext.v[c];
-        load_loader(wa, s + 1, hk);
-        if (s & 1) slots_down<W - 1>(wa, s, prev, Onew, H2, hk);
-        else slots_down<W - 1>(wa, s, prev, Onew, H, hk);
+        for (int c = 0; c < 3; c++) Onew[0][c] = Lnext.v[c];  // the loader's output of this step
+        load_loader(wa, tb, s + 1, hk);
+        WIN_SCHED_FENCE();
+        slots_down<W - 1>(wa, tb, s, lds, (s - 1) & 1, Onew, Hnew, hk);
+        const int pc = s & 1;
 #pragma unroll
         for (int q = 0; q <= W; q++)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                cur[q][c][tid] = Onew[q][c];
+                lds.O[pc][q][c][tid] = Onew[q][c];
                 Om2[q][c] = Om1[q][c];
                 Om1[q][c] = Onew[q][c];
             }
+        // taken-over lines: slot q's history of the next step is the import (voxel i+1 now, its own old value then)
+#pragma unroll
+        for (int q = 1; q < W; q++) {
+            const bool ia = q == qa, ib = q == qb && qa != qb;
+#pragma unroll
+            for (int c = 0; c < 3; c++) Om1[q][c] = sel(ia, SWa.v[c], sel(ib, SWb.v[c], Om1[q][c]));
+#pragma unroll
+            for (int n = 0; n < 9; n++) {
+                H2[q][n] = sel(ia, SMa.v[n], sel(ib, SMb.v[n], H1[q][n]));
+                H1[q][n] = Hnew[q][n];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            lds.imp[WIN_IMP_ZM][c][tid] = NBa.v[c];
+            lds.imp[WIN_IMP_YM][c][tid] = NBb.v[c];
+            lds.imp[WIN_IMP_YP_SW][c][tid] = SXa.v[c];
+            lds.imp[WIN_IMP_ZP_SW][c][tid] = SXb.v[c];
+            lds.imp[WIN_IMP_ZP_TOP][c][tid] = TOPa.v[c];
+            lds.imp[WIN_IMP_YP_TOP][c][tid] = TOPb.v[c];
+        }
     }
 };
+
+#define WIN_LEAD 4  // steps the kernel runs ahead of the tile's first voxel: the prefetch pipelines fill (3 needed)
 
 }  // namespace fr3d

@@ -136,7 +136,8 @@ class HipExecutor3D:
         params = _lib.make_params(alpha, fp.get("update_lag", 10), fp.get("iterations", 20),
                                   fp.get("min_level", 0), fp.get("levels", 50), fp.get("eta", 0.8), a_smooth,
                                   fp.get("a_data", 0.45), nc,
-                                  None if fp.get("solver_fp64") is None else int(fp["solver_fp64"]))
+                                  None if fp.get("solver_fp64") is None else int(fp["solver_fp64"]),
+                                  int(fp.get("solver_sweep") or 0))
         wt = None if is_default_weight(fp.get("weight", None), nc) else expand_weight(fp.get("weight", None), Z, Y, X, nc)
 
         def f32(a, shape):
@@ -202,7 +203,8 @@ class HipExecutor3D:
         params = _lib.make_params(fp.get("alpha", (2, 2, 2)), fp.get("update_lag", 10), fp.get("iterations", 20),
                                   fp.get("min_level", 0), fp.get("levels", 50), fp.get("eta", 0.8),
                                   float(fp.get("a_smooth", 0.5)), fp.get("a_data", 0.45), nc,
-                                  None if fp.get("solver_fp64") is None else int(fp["solver_fp64"]))
+                                  None if fp.get("solver_fp64") is None else int(fp["solver_fp64"]),
+                                  int(fp.get("solver_sweep") or 0))
         raw_code = _RAW_CODES.get(batch.dtype)
         br = np.ascontiguousarray(batch if raw_code is not None else batch.astype(np.float64))
         code = raw_code if raw_code is not None else _lib.F64

@@ -59,9 +59,19 @@ typedef struct fr3d_params {
                                              1e-4 voxels of the reference CPU path with margin -- one channel: 1 up
                                              to 2^22 voxels, 3 above; several channels: 2 (what the Python mirror
                                              passes by default) */
-    int reserved[7];
+    int solver_sweep;                  /* which kernel runs the a_smooth == 1 sweep (results are bit-identical):
+                                          FR3D_SWEEP_AUTO (0): the engine's choice per level;
+                                          FR3D_SWEEP_PLANES (1): one launch per hyperplane step, every iteration's
+                                             operands streamed from HBM (k_sor.hip);
+                                          FR3D_SWEEP_WINDOW (2): a whole psi window (update_lag iterations) per
+                                             workgroup on chip, tiles of lines marching along x (k_sor_win.hip;
+                                             1 or 2 channels, PLANES otherwise) */
+    int reserved[6];
 } fr3d_params;
 #define FR3D_SOLVER_AUTO (-1)
+#define FR3D_SWEEP_AUTO 0
+#define FR3D_SWEEP_PLANES 1
+#define FR3D_SWEEP_WINDOW 2
 
 /* The solver mode (0..3) the most recent flow solve of this process ran in: what FR3D_SOLVER_AUTO resolved to.  An
  * automatic choice of packed storage falls back to fp32 storage when one volume's packed solver slabs do not fit the

@@ -109,7 +109,8 @@ static int run(int Z, int Y, int X, int T, int lag, unsigned seed)
     // ---- emulation of the window kernel ----
     constexpr int W = WIN_WMAX;
     std::vector<S> Mw = M0, dw = d0;
-    std::vector<std::vector<S>> E(W - 1, d0);
+    std::vector<S> E((size_t)(W - 1) * e3);
+    memset(E.data(), 0, E.size() * sizeof(S));
     WinArgs<S> wa;
     memset(&wa, 0, sizeof(wa));
     wa.a.M = Mw.data();
@@ -119,11 +120,13 @@ static int run(int Z, int Y, int X, int T, int lag, unsigned seed)
     wa.a.sk = sk;
     wa.a.ax = ax; wa.a.ay = ay; wa.a.az = az;
     wa.a.C = C; wa.a.iterations = T; wa.a.update_lag = lag; wa.a.nvol = 1;
-    for (int q = 0; q < W - 1; q++) wa.E[q] = E[q].data();
+    wa.E = E.data();
+    wa.strideE = (long long)e3;
+    const WinTabPtr tb{pb.data(), cp.data()};
     const WinSchedHost sc = make_win_schedule(Z, Y, T, lag, W);
     Shadow sh[2 + W - 1];
     for (auto &s : sh) s.init((size_t)total);
-    using Th = WinThread<R, S, C, W, EmuHook>;
+    using Th = WinThread<R, S, C, W, WinTabPtr, EmuHook>;
     std::vector<Th> th(WIN_NT);
     static WinLds<V, W> lds;
     long long wg = 0, steps = 0;
@@ -135,15 +138,9 @@ static int run(int Z, int Y, int X, int T, int lag, unsigned seed)
             int s0, s1;
             Th::step_range(sk, tl, s0, s1);
             memset(&lds, 0, sizeof(lds));
-            for (int tid = 0; tid < WIN_NT; tid++) {
-                th[tid].init(wa, tl, 0, tid, win, sc.windows[win].win_build);
-                th[tid].prime(wa, s0, hk);
-            }
-            // the loader outputs of step s0 - 1 are read from LDS in step s0
-            for (int tid = 0; tid < WIN_NT; tid++)
-                for (int c = 0; c < 3; c++) lds.O[(s0 - 1) & 1][0][c][tid] = th[tid].Om1[0][c];
-            for (int s = s0; s <= s1; s++) {
-                for (int tid = 0; tid < WIN_NT; tid++) th[tid].step(wa, s, lds.O[(s - 1) & 1], lds.O[s & 1], hk);
+            for (int tid = 0; tid < WIN_NT; tid++) th[tid].init(wa, tl, 0, tid, win, sc.windows[win].win_build);
+            for (int s = s0 - WIN_LEAD; s <= s1; s++) {
+                for (int tid = 0; tid < WIN_NT; tid++) th[tid].step(wa, tb, s, lds, hk);
                 steps++;
             }
             wg++;
