@@ -379,8 +379,8 @@ long long launch_sor(hipStream_t st, const SorArgsT<S> &a, bool fp64, const SorC
 struct WinTile;
 template <typename S> struct WinArgs;
 struct WinSched {
-    std::vector<int> first, count;  // per launch
-    WinTile *tiles = nullptr;       // device
+    std::vector<int> first, count, nbuild;  // per launch: its tiles, how many of them (the first ones) build their system
+    WinTile *tiles = nullptr;               // device
 };
 WinSched build_win_schedule(const Skew &sk, int iterations, int update_lag);
 void free_win_schedule(WinSched &ws);

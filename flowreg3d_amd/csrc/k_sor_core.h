@@ -92,6 +92,44 @@ FR3D_HD Rec<S, N> ldrec(const S *base, long long voxel)
         return *reinterpret_cast<const Rec<S, N> *>(base + voxel * N);
     }
 }
+// A record as it lies in memory: loading it does not touch the loaded bits (ldrec decodes packed values at once, which
+// makes the consumer of a PREFETCH wait for the data where the load is issued); dec() decodes at the point of use.
+template <typename S, int N>
+struct RawRec {
+    typename Sto<S>::val w[N];
+    FR3D_HD Rec<S, N> dec() const
+    {
+        Rec<S, N> r;
+#pragma unroll
+        for (int n = 0; n < N; n++) r.v[n] = w[n];
+        return r;
+    }
+};
+template <int N>
+struct RawRec<pk42, N> {
+    static_assert(N % 3 == 0, "pk42 records hold triples");
+    uint4 w[N / 3];
+    FR3D_HD Rec<pk42, N> dec() const
+    {
+        Rec<pk42, N> r;
+#pragma unroll
+        for (int g = 0; g < N / 3; g++) {
+            const uint4 q = w[g];
+            r.v[3 * g + 0] = bits_double(q.x, (q.w & 0x3FFu) << 22);
+            r.v[3 * g + 1] = bits_double(q.y, ((q.w >> 10) & 0x3FFu) << 22);
+            r.v[3 * g + 2] = bits_double(q.z, (q.w >> 20) << 22);
+        }
+        return r;
+    }
+};
+template <typename S, int N>
+FR3D_HD RawRec<S, N> ldraw(const S *base, long long voxel)
+{
+    if constexpr (std::is_same<S, pk42>::value)
+        return *reinterpret_cast<const RawRec<S, N> *>(reinterpret_cast<const uint4 *>(base) + voxel * (N / 3));
+    else
+        return *reinterpret_cast<const RawRec<S, N> *>(base + voxel * N);
+}
 // values must already be representable (Sto<S>::quant) -- the bits below the format are dropped
 template <typename S, int N>
 FR3D_HD void strec(S *base, long long voxel, const Rec<S, N> &r)

@@ -24,13 +24,12 @@ struct WinTabLds {
 };
 static size_t win_table_bytes(const Skew &sk) { return (size_t)(sk.S + 2) * 8 + (size_t)(sk.X + sk.Y + 2) * 4; }
 
-template <typename R, typename S, int C, int W>
+template <typename R, typename S, int C, int W, bool BUILD>
 __global__ void __launch_bounds__(WIN_NT)
 k_sor_win(const WinArgs<S> wa, const WinTile *__restrict__ tiles)
 {
-    using Th = WinThread<R, S, C, W, WinTabLds>;
-    using V = typename Th::V;
-    __shared__ WinLds<V, W> lds;
+    using Th = WinThread<R, S, C, W, BUILD, WinTabLds>;
+    __shared__ typename Th::Lds lds;
     const WinTile tl = tiles[blockIdx.x];
     const int tid = (int)threadIdx.x;
     const Skew &sk = wa.a.sk;
@@ -41,6 +40,7 @@ k_sor_win(const WinArgs<S> wa, const WinTile *__restrict__ tiles)
     for (int n = tid; n < sk.X + sk.Y + 2; n += WIN_NT) cpl[n] = sk.cp[n];
     Th th;
     th.init(wa, tl, (int)blockIdx.y, tid, 0, 0);
+    th.init_lds(lds);
     int s0, s1;
     Th::step_range(sk, tl, s0, s1);
     const WinNoHook hk;
@@ -57,6 +57,7 @@ WinSched build_win_schedule(const Skew &sk, int iterations, int update_lag)
     const WinSchedHost h = make_win_schedule(sk.Z, sk.Y, iterations, update_lag, WIN_WMAX);
     ws.first = h.first;
     ws.count = h.count;
+    ws.nbuild = h.nbuild;
     if (!h.tiles.empty()) {
         FR3D_HIP(hipMalloc((void **)&ws.tiles, h.tiles.size() * sizeof(WinTile)));
         FR3D_HIP(hipMemcpy(ws.tiles, h.tiles.data(), h.tiles.size() * sizeof(WinTile), hipMemcpyHostToDevice));
@@ -75,10 +76,12 @@ bool sor_win_supports(int C) { return C >= 1 && C <= 2; }
 bool sor_win_fits(const Skew &sk) { return sk.pb != nullptr && win_table_bytes(sk) <= 48 * 1024; }
 
 template <typename R, typename S, int C>
-static void launch_win_step(hipStream_t st, const WinArgs<S> &wa, const WinTile *tiles, int count)
+static void launch_win_step(hipStream_t st, const WinArgs<S> &wa, const WinTile *tiles, int count, bool build)
 {
+    if (count <= 0) return;
     const dim3 grid(count, wa.a.nvol > 0 ? wa.a.nvol : 1), block(WIN_NT);
-    hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
+    if (build) hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX, true>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
+    else hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX, false>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
     FR3D_LAUNCH_CHECK();
 }
 
@@ -90,16 +93,21 @@ long long launch_sor_win(hipStream_t st, const WinArgs<S> &wa, bool fp64, const 
     long long launches = 0;
     for (size_t l = 0; l < ws.first.size(); l++) {
         if (ws.count[l] <= 0) continue;
-        const WinTile *tiles = ws.tiles + ws.first[l];
-        const bool r64 = Sto<S>::wide || fp64;
-        if (wa.a.C == 1) {
-            if (r64) launch_win_step<double, S, 1>(st, wa, tiles, ws.count[l]);
-            else if constexpr (!Sto<S>::wide) launch_win_step<float, S, 1>(st, wa, tiles, ws.count[l]);
-        } else {
-            if (r64) launch_win_step<double, S, 2>(st, wa, tiles, ws.count[l]);
-            else if constexpr (!Sto<S>::wide) launch_win_step<float, S, 2>(st, wa, tiles, ws.count[l]);
+        // the tiles of a launch: first those of windows that build their system, then those that read it (two kernels)
+        for (int part = 0; part < 2; part++) {
+            const int n = part == 0 ? ws.nbuild[l] : ws.count[l] - ws.nbuild[l];
+            if (n <= 0) continue;
+            const WinTile *tiles = ws.tiles + ws.first[l] + (part == 0 ? 0 : ws.nbuild[l]);
+            const bool r64 = Sto<S>::wide || fp64;
+            if (wa.a.C == 1) {
+                if (r64) launch_win_step<double, S, 1>(st, wa, tiles, n, part == 0);
+                else if constexpr (!Sto<S>::wide) launch_win_step<float, S, 1>(st, wa, tiles, n, part == 0);
+            } else {
+                if (r64) launch_win_step<double, S, 2>(st, wa, tiles, n, part == 0);
+                else if constexpr (!Sto<S>::wide) launch_win_step<float, S, 2>(st, wa, tiles, n, part == 0);
+            }
+            launches++;
         }
-        launches++;
     }
     return launches;
 }

@@ -59,14 +59,24 @@ struct WinArgs {
     long long strideE;       // strided (per volume) like d
 };
 
-// LDS image of one workgroup: outputs of step s-1 (and s) of slot -1 (the loader) .. W-1, structure of arrays; and
-// each thread's own "import" records (neighbour values that come from another tile): a thread that needs one reads its
-// import slot INSTEAD of the neighbouring thread's output -- one select on the LDS address, not one per value.
-enum { WIN_IMP_ZM = 0, WIN_IMP_YM = 1, WIN_IMP_YP_SW = 2, WIN_IMP_ZP_SW = 3, WIN_IMP_ZP_TOP = 4, WIN_IMP_YP_TOP = 5, WIN_IMP_N = 6 };
-template <typename V, int W>
+// LDS image of one workgroup:
+//  * O: outputs of step s-1 (and s) of slot -1 (the loader) .. W-1, structure of arrays;
+//  * stg: every thread's PRIVATE staging of the operands it requested from HBM for the next step (the loader's record,
+//    slot 0's factors / weights / Laplacian terms or stored system): requested at the top of a step, parked here at its
+//    bottom, read where slot 0 needs them one step later.  Loop-carried LOADED registers made the compiler wait for the
+//    data (and copy it into the loop's registers) right where the load is issued; values that live in LDS between
+//    the steps leave only computed scalars as loop-carried state;
+//  * imp: the neighbour values a thread gets from another tile instead of from the neighbouring thread (compact: only
+//    5 of the 16 rows / columns of threads ever import): the slot reads its import entry INSTEAD of the neighbour's
+//    output -- one select on the LDS address, not one per value.
+#define WIN_NSPEC (5 * 16)  // threads that are ever the bottom of a slot's range in one direction: a (b) in {0, 12..15}
+template <typename V, int W, int NSTG>
 struct WinLds {
     V O[2][W + 1][3][WIN_NT];
-    V imp[WIN_IMP_N][3][WIN_NT];
+    unsigned stg[NSTG][WIN_NT];
+    V imp_zm[WIN_NSPEC][3], imp_ypsw[WIN_NSPEC][3];  // direction a: -1 neighbour in k; +1 neighbour in j of a taken-over line
+    V imp_ym[WIN_NSPEC][3], imp_zpsw[WIN_NSPEC][3];  // direction b
+    V imp_zptop[WIN_BJ][3], imp_yptop[WIN_BK][3];    // slot 0, top row / column
 };
 
 // Row-start tables of the compact skewed layout (Skew::pb / cp) as the kernel sees them: the device keeps copies in
@@ -101,35 +111,31 @@ enum { WIN_ARR_D = 0, WIN_ARR_M = 1, WIN_ARR_E0 = 2 };  // array ids of the hook
 #define WIN_ANY(c) (c)
 #endif
 
-template <typename R, typename S, int C, int W, typename Tab = WinTabPtr, typename Hook = WinNoHook>
+template <typename R, typename S, int C, int W, bool BUILD, typename Tab = WinTabPtr, typename Hook = WinNoHook>
 struct WinThread {
     using V = typename Sto<S>::val;
+    using WT = typename StoWt<S>::type;
     static_assert(W >= 1 && W <= WIN_WMAX, "window slots");
     static_assert(C >= 1, "channel count is a template parameter");
+    // 32-bit words of the staged operands of one thread
+    static constexpr int NW3 = sizeof(RawRec<S, 3>) / 4, NW9 = sizeof(RawRec<S, 9>) / 4, NW12 = sizeof(RawRec<S, 12>) / 4;
+    static constexpr int NWT = sizeof(WT) / 4;
+    static constexpr int NSTG = NW3 + (BUILD ? C * (NW12 + NWT) + NW3 : NW9);
+    using Lds = WinLds<V, W, NSTG>;
 
     // ---- constant per thread ----
     int a, b, tid;
     int K, J, nsl;
-    bool build, storeM;
-    int qa, qb;  // the slot in which this thread is the bottom of the range in a / in b (>= W: never)
+    bool storeM;
+    int qa, qb;    // the slot in which this thread is the bottom of the range in a / in b (>= W: never)
+    int ixa, ixb;  // its entry in the import arrays of that direction
     int Z, Y, X;
     long long vD, vM, vA, vL;  // volume offsets (storage elements)
     int win, win_build;        // window of this workgroup / of the psi update its system belongs to (hook versions)
 
-    // ---- state ----
-    V Om1[W + 1][3], Om2[W + 1][3];  // slot q's line in slot q-1 (the loader for q = 0), steps s-1 and s-2: its i+1 neighbour, its own old value
-    V H1[W][9], H2[W][9];            // frozen systems on their way to slot q: H2[q] is read in this step, H1[q] in the next
-    // prefetched for the next step
-    Rec<S, 3> Lnext;                 // loader: d of the slot-0 line, two voxels ahead of slot 0
-    Rec<S, 12> fr[C];
-    double wt[C];
-    Rec<S, 3> lr;                    // build: Laplacian terms
-    Rec<S, 9> mx;                    // no build: the stored system
-    Rec<S, 3> NBa, NBb;              // -1 neighbour across the tile edge (slot qa / qb)
-    Rec<S, 3> SWa, SWb;              // taken-over line: the i+1 neighbour of the next step's voxel (becomes its own old value a step later)
-    Rec<S, 3> SXa, SXb;              // taken-over line: +1 neighbour in the other direction (same exported row)
-    Rec<S, 9> SMa, SMb;              // taken-over line: frozen system
-    Rec<S, 3> TOPa, TOPb;            // slot 0, top row / column: +1 neighbour of the previous window (d)
+    // ---- loop-carried state: computed values only ----
+    V Om1[W][3], Om2[W][3];  // slot q's line in slot q-1 (the loader for q = 0), steps s-1 and s-2: its i+1 neighbour, its own old value
+    V H1[W][9], H2[W][9];    // frozen systems on their way to slot q: H2[q] is read in this step, H1[q] in the next
 
     FR3D_HD static int kline(int K, int a, int q) { return K * WIN_BK + a - (a >= WIN_BK - q ? WIN_BK : 0); }
     FR3D_HD static int jline(int J, int b, int q) { return J * WIN_BJ + b - (b >= WIN_BJ - q ? WIN_BJ : 0); }
@@ -141,11 +147,24 @@ struct WinThread {
     // ADDRESSES inside the thread object and keeps the whole object in scratch memory (no scalar replacement)
     FR3D_HD static V sel(bool c, V x, V y) { return c ? x : y; }
 
-    template <int N>
-    FR3D_HD static void zero(Rec<S, N> &r)
+    // a raw record <-> this thread's staging words
+    template <typename T>
+    FR3D_HD void stage_put(Lds &lds, int w0, const T &r) const
     {
+        static_assert(sizeof(T) % 4 == 0, "staged types are whole words");
+        struct Words { unsigned w[sizeof(T) / 4]; };
+        const Words x = __builtin_bit_cast(Words, r);
 #pragma unroll
-        for (int n = 0; n < N; n++) r.v[n] = 0;
+        for (int n = 0; n < (int)(sizeof(T) / 4); n++) lds.stg[w0 + n][tid] = x.w[n];
+    }
+    template <typename T>
+    FR3D_HD T stage_get(const Lds &lds, int w0) const
+    {
+        struct Words { unsigned w[sizeof(T) / 4]; };
+        Words x;
+#pragma unroll
+        for (int n = 0; n < (int)(sizeof(T) / 4); n++) x.w[n] = lds.stg[w0 + n][tid];
+        return __builtin_bit_cast(T, x);
     }
 
     FR3D_HD void init(const WinArgs<S> &wa, const WinTile &tl, int vol, int tid_, int win_, int win_build_)
@@ -156,29 +175,31 @@ struct WinThread {
         b = tid % WIN_BJ;
         K = tl.K; J = tl.J;
         nsl = tl.info & 0xff;
-        build = (tl.info >> 8) & 1;
         storeM = (tl.info >> 9) & 1;
         win = win_; win_build = win_build_;
         qa = (WIN_BK - a) % WIN_BK;
         qb = (WIN_BJ - b) % WIN_BJ;
+        ixa = (qa < WIN_WMAX ? qa : 0) * WIN_BJ + b;
+        ixb = (qb < WIN_WMAX ? qb : 0) * WIN_BK + a;
         Z = A_.sk.Z; Y = A_.sk.Y; X = A_.sk.X;
         vD = vol * A_.vsD; vM = vol * A_.vsM; vA = vol * A_.vsA; vL = vol * A_.vsL;
 #pragma unroll
-        for (int q = 0; q <= W; q++)
+        for (int q = 0; q < W; q++) {
 #pragma unroll
             for (int c = 0; c < 3; c++) Om1[q][c] = Om2[q][c] = 0;
 #pragma unroll
-        for (int q = 0; q < W; q++)
-#pragma unroll
             for (int n = 0; n < 9; n++) H1[q][n] = H2[q][n] = 0;
-        zero(Lnext); zero(lr); zero(mx); zero(NBa); zero(NBb); zero(SWa); zero(SWb);
-        zero(SXa); zero(SXb); zero(SMa); zero(SMb); zero(TOPa); zero(TOPb);
+        }
+    }
+    // the staging words of this thread start out as zeros (they are read before the first request has been parked)
+    FR3D_HD void init_lds(Lds &lds) const
+    {
 #pragma unroll
-        for (int c = 0; c < C; c++) { zero(fr[c]); wt[c] = 0; }
+        for (int n = 0; n < NSTG; n++) lds.stg[n][tid] = 0u;
     }
 
     // first step in which any slot of this tile has a voxel, and the last one; the kernel starts WIN_LEAD steps
-    // earlier, with every slot still idle, so that the prefetch pipelines fill through the ordinary step code
+    // earlier, with every slot still idle, so that the request pipelines fill through the ordinary step code
     FR3D_HD static void step_range(const Skew &sk, const WinTile &tl, int &s_first, int &s_last)
     {
         const int nsl = tl.info & 0xff;
@@ -190,55 +211,71 @@ struct WinThread {
         s_last = khi + jhi + (sk.X - 1) + 2 * (nsl - 1);
     }
 
-    // ---- the prefetches of step s_next, issued one step ahead ----
+    // What a thread requests from HBM at the top of step s for step s + 1 (all step-local).
+    struct Req {
+        RawRec<S, 3> L;                   // loader: d of the slot-0 line at voxel (s + 1) + 2 - k - j
+        RawRec<S, 12> fr[C];              // BUILD: slot 0's factors, weights, Laplacian terms
+        WT wt[C];
+        RawRec<S, 3> lr;
+        RawRec<S, 9> mx;                  // !BUILD: the stored system
+        RawRec<S, 3> NBa, NBb;            // -1 neighbour across the tile edge (slot qa / qb)
+        RawRec<S, 3> SWa, SWb;            // taken-over line: the i+1 neighbour of step s+1 (one step later the voxel's own old value)
+        RawRec<S, 3> SXa, SXb;            // taken-over line: +1 neighbour in the other direction (same exported row)
+        RawRec<S, 9> SMa, SMb;            // taken-over line: frozen system
+        RawRec<S, 3> TOPa, TOPb;          // slot 0, top row / column: +1 neighbour of the previous window (d)
+    };
+
     // Every thread's own-line operands: unconditional loads at clamped coordinates (a voxel outside the volume reads a
-    // valid record that nobody uses), so the compiler can count the loads in flight instead of draining them at a join.
-    FR3D_HD void load_loader(const WinArgs<S> &wa, const Tab &tb, int s_next, const Hook &hk)
+    // valid record that nobody uses), so that nothing merges a loaded value with an older one.
+    FR3D_HD void request_own(const WinArgs<S> &wa, const Tab &tb, int s_next, Req &rq, const Hook &hk) const
     {
-        // O_{-1}(s) = d of the slot-0 line at voxel s + 2 - k - j
-        const int k = kq(0), j = jq(0), i = s_next + 2 - k - j;
+        const int k = kq(0), j = jq(0);
+        const int kc = clampi(k, 0, Z - 1), jc = clampi(j, 0, Y - 1);
+        {
+            const int i = s_next + 2 - k - j;
+            const long long e = win_index(tb, X, kc, jc, clampi(i, 0, X - 1));
+            if (line_ok(k, j) && i >= 0 && i < X) hk.rd(WIN_ARR_D, e, win - 1);
+            rq.L = ldraw<S, 3>(wa.a.d + vD, e);
+        }
+        const int i = s_next - k - j;
         const bool ok = line_ok(k, j) && i >= 0 && i < X;
-        const long long e = win_index(tb, X, clampi(k, 0, Z - 1), clampi(j, 0, Y - 1), clampi(i, 0, X - 1));
-        if (ok) hk.rd(WIN_ARR_D, e, win - 1);
-        Lnext = ldrec<S, 3>(wa.a.d + vD, e);
-    }
-    FR3D_HD void load_slot0(const WinArgs<S> &wa, const Tab &tb, int s_next, const Hook &hk)
-    {
-        const int k = kq(0), j = jq(0), i = s_next - k - j;
-        const bool ok = line_ok(k, j) && i >= 0 && i < X;
-        const long long e = win_index(tb, X, clampi(k, 0, Z - 1), clampi(j, 0, Y - 1), clampi(i, 0, X - 1));
-        if (build) {
+        const long long e = win_index(tb, X, kc, jc, clampi(i, 0, X - 1));
+        if constexpr (BUILD) {
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                fr[c] = ldrec<S, 12>(wa.a.A[c] + vA, e);
-                wt[c] = (double)wa.a.weight[c][e];
+                rq.fr[c] = ldraw<S, 12>(wa.a.A[c] + vA, e);
+                rq.wt[c] = wa.a.weight[c][e];
             }
-            lr = ldrec<S, 3>(wa.a.L + vL, e);
+            rq.lr = ldraw<S, 3>(wa.a.L + vL, e);
         } else {
             if (ok) hk.rd(WIN_ARR_M, e, win_build);
-            mx = ldrec<S, 9>(wa.a.M + vM, e);
+            rq.mx = ldraw<S, 9>(wa.a.M + vM, e);
         }
     }
     // slot 0, top row / column: the +1 neighbour belongs to the tile above; its value of the previous window is in d
-    FR3D_HD void load_top(const WinArgs<S> &wa, const Tab &tb, int s_next, const Hook &hk)
+    FR3D_HD void request_top(const WinArgs<S> &wa, const Tab &tb, int s_next, Req &rq, const Hook &hk) const
     {
+        rq.TOPa = RawRec<S, 3>{};
+        rq.TOPb = RawRec<S, 3>{};
         const int k = kq(0), j = jq(0), i = s_next - k - j;
         if (!(line_ok(k, j) && i >= 0 && i < X)) return;
         if (a == WIN_BK - 1 && k + 1 < Z) {
             const long long en = win_index(tb, X, k + 1, j, i);
             hk.rd(WIN_ARR_D, en, win - 1);
-            TOPa = ldrec<S, 3>(wa.a.d + vD, en);
+            rq.TOPa = ldraw<S, 3>(wa.a.d + vD, en);
         }
         if (b == WIN_BJ - 1 && j + 1 < Y) {
             const long long en = win_index(tb, X, k, j + 1, i);
             hk.rd(WIN_ARR_D, en, win - 1);
-            TOPb = ldrec<S, 3>(wa.a.d + vD, en);
+            rq.TOPb = ldraw<S, 3>(wa.a.d + vD, en);
         }
     }
     // the imports of a thread that is the bottom of the range in a (dir 0) or in b (dir 1), in its slot q = qa / qb
     template <int dir>
-    FR3D_HD void load_special(const WinArgs<S> &wa, const Tab &tb, int q, int s_next, const Hook &hk)
+    FR3D_HD void request_special(const WinArgs<S> &wa, const Tab &tb, int q, int s_next, RawRec<S, 3> &NB,
+                                 RawRec<S, 3> &SW, RawRec<S, 3> &SX, RawRec<S, 9> &SM, const Hook &hk) const
     {
+        NB = RawRec<S, 3>{}; SW = RawRec<S, 3>{}; SX = RawRec<S, 3>{}; SM = RawRec<S, 9>{};
         if (q >= nsl) return;
         const int k = kq(q), j = jq(q), i = s_next - 2 * q - k - j;
         if (!line_ok(k, j)) return;
@@ -250,7 +287,7 @@ struct WinThread {
             const long long e = win_index(tb, X, kn, jn, i);
             hk.rd(last ? WIN_ARR_D : WIN_ARR_E0 + q, e, win);
             const S *src = last ? wa.a.d + vD : wa.E + (long long)q * wa.strideE + vD;
-            (dir == 0 ? NBa : NBb) = ldrec<S, 3>(src, e);
+            NB = ldraw<S, 3>(src, e);
         }
         if (q == 0) return;
         const S *Eprev = wa.E + (long long)(q - 1) * wa.strideE + vD;
@@ -261,12 +298,12 @@ struct WinThread {
             if (i + 1 >= 0 && i + 1 < X) {
                 const long long e = win_index(tb, X, k, j, i + 1);
                 hk.rd(WIN_ARR_E0 + q - 1, e, win);
-                (dir == 0 ? SWa : SWb) = ldrec<S, 3>(Eprev, e);
+                SW = ldraw<S, 3>(Eprev, e);
             }
             if (in) {
                 const long long e = win_index(tb, X, k, j, i);
                 hk.rd(WIN_ARR_M, e, win_build);
-                (dir == 0 ? SMa : SMb) = ldrec<S, 9>(wa.a.M + vM, e);
+                SM = ldraw<S, 9>(wa.a.M + vM, e);
             }
         }
         // the +1 neighbour in the OTHER direction lies on the same exported row / column
@@ -274,17 +311,17 @@ struct WinThread {
         if (in && kx < Z && jx < Y) {
             const long long e = win_index(tb, X, kx, jx, i);
             hk.rd(WIN_ARR_E0 + q - 1, e, win);
-            (dir == 0 ? SXa : SXb) = ldrec<S, 3>(Eprev, e);
+            SX = ldraw<S, 3>(Eprev, e);
         }
     }
 
     // ---- one slot of one step ----
     // The line's own history (Om1/Om2) and its system record (H2) already hold the imported values where the line was
-    // taken over (end_of_step), so the slot body has no special cases except WHERE the four cross-line neighbours are
-    // read from, and the ghosts at the volume's faces (a wave-uniform branch: most waves have none).
+    // taken over (end of step()), so the slot body has no special cases except WHERE the four cross-line neighbours
+    // are read from, and the ghosts at the volume's faces (a wave-uniform branch: most waves have none).
     template <int q>
-    FR3D_HD void slot(const WinArgs<S> &wa, const Tab &tb, int s, const WinLds<V, W> &lds, int pp, V (&Onew)[W + 1][3],
-                      V (&Hnew)[W][9], const Hook &hk)
+    FR3D_HD void slot(const WinArgs<S> &wa, const Tab &tb, int s, Lds &lds, int pp, V (&Onew)[W + 1][3], V (&Hnew)[W][9],
+                      const Hook &hk)
     {
         const SorArgsT<S> &A_ = wa.a;
         const int k = kq(q), j = jq(q), i = s - 2 * q - k - j;
@@ -293,26 +330,32 @@ struct WinThread {
         V own[3], xp[3], xm[3], yp[3], ym[3], zp[3], zm[3], sys[9];
         const int t_am = ((a + WIN_BK - 1) % WIN_BK) * WIN_BJ + b, t_ap = ((a + 1) % WIN_BK) * WIN_BJ + b;
         const int t_bm = a * WIN_BJ + (b + WIN_BJ - 1) % WIN_BJ, t_bp = a * WIN_BJ + (b + 1) % WIN_BJ;
-        // -1 neighbours: this slot, step s-1;  +1 neighbours: slot q-1 (q = 0: the loader), step s-1; or the import slot
-        const V *pzm = spa ? &lds.imp[WIN_IMP_ZM][0][tid] : &lds.O[pp][q + 1][0][t_am];
-        const V *pym = spb ? &lds.imp[WIN_IMP_YM][0][tid] : &lds.O[pp][q + 1][0][t_bm];
+        // -1 neighbours: this slot, step s-1;  +1 neighbours: slot q-1 (q = 0: the loader), step s-1; or the import
+        // entry (component stride 1 there, WIN_NT in the output arrays)
+        const V *pzm = spa ? &lds.imp_zm[ixa][0] : &lds.O[pp][q + 1][0][t_am];
+        const V *pym = spb ? &lds.imp_ym[ixb][0] : &lds.O[pp][q + 1][0][t_bm];
+        const int szm = spa ? 1 : WIN_NT, sym = spb ? 1 : WIN_NT;
         const V *pzp, *pyp;
+        int szp, syp;
         if (q == 0) {
-            pzp = a == WIN_BK - 1 ? &lds.imp[WIN_IMP_ZP_TOP][0][tid] : &lds.O[pp][q][0][t_ap];
-            pyp = b == WIN_BJ - 1 ? &lds.imp[WIN_IMP_YP_TOP][0][tid] : &lds.O[pp][q][0][t_bp];
+            const bool ta = a == WIN_BK - 1, tb_ = b == WIN_BJ - 1;
+            pzp = ta ? &lds.imp_zptop[b][0] : &lds.O[pp][q][0][t_ap];
+            pyp = tb_ ? &lds.imp_yptop[a][0] : &lds.O[pp][q][0][t_bp];
+            szp = ta ? 1 : WIN_NT; syp = tb_ ? 1 : WIN_NT;
         } else {
-            pzp = spb ? &lds.imp[WIN_IMP_ZP_SW][0][tid] : &lds.O[pp][q][0][t_ap];
-            pyp = spa ? &lds.imp[WIN_IMP_YP_SW][0][tid] : &lds.O[pp][q][0][t_bp];
+            pzp = spb ? &lds.imp_zpsw[ixb][0] : &lds.O[pp][q][0][t_ap];
+            pyp = spa ? &lds.imp_ypsw[ixa][0] : &lds.O[pp][q][0][t_bp];
+            szp = spb ? 1 : WIN_NT; syp = spa ? 1 : WIN_NT;
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             own[c] = Om2[q][c];
             xp[c] = Om1[q][c];
-            // i-1 neighbour: this thread's own output of step s-1.  From LDS, not from Om1[q + 1]: where slot q+1
-            // takes another line over, that entry holds the other line's import
+            // i-1 neighbour: this thread's own output of step s-1 (Om1[q + 1] holds another line's import where
+            // slot q+1 takes a line over)
             xm[c] = lds.O[pp][q + 1][c][tid];
-            zm[c] = pzm[c * WIN_NT]; ym[c] = pym[c * WIN_NT];
-            zp[c] = pzp[c * WIN_NT]; yp[c] = pyp[c * WIN_NT];
+            zm[c] = pzm[c * szm]; ym[c] = pym[c * sym];
+            zp[c] = pzp[c * szp]; yp[c] = pyp[c * syp];
         }
         // Neumann ghosts (set_boundary_3d :246-259): a missing neighbour is the voxel's own old value
         const bool ghost = i <= 0 || i >= X - 1 || j == 0 || j == Y - 1 || k == 0 || k == Z - 1;
@@ -330,12 +373,15 @@ struct WinThread {
         // the frozen system
         if (q == 0) {
             Rec<S, 9> mr;
-            if (build) {
+            if constexpr (BUILD) {
                 SorAcc<R> acc;
 #pragma unroll
-                for (int c = 0; c < C; c++)
-                    sor_accum_channel<R, S>(fr[c], wt[c], A_.a_data[c], (R)own[0], (R)own[1], (R)own[2], acc);
-                mr = sor_finish_system<R, S>(acc, lr);
+                for (int c = 0; c < C; c++) {
+                    const RawRec<S, 12> f = stage_get<RawRec<S, 12>>(lds, NW3 + c * (NW12 + NWT));
+                    const WT w = stage_get<WT>(lds, NW3 + c * (NW12 + NWT) + NW12);
+                    sor_accum_channel<R, S>(f.dec(), (double)w, A_.a_data[c], (R)own[0], (R)own[1], (R)own[2], acc);
+                }
+                mr = sor_finish_system<R, S>(acc, stage_get<RawRec<S, 3>>(lds, NW3 + C * (NW12 + NWT)).dec());
                 // lines that another tile takes over later need the record in memory
                 if (active && (storeM || a >= WIN_BK - W + 1 || b >= WIN_BJ - W + 1)) {
                     const long long e = win_index(tb, X, k, j, i);
@@ -343,12 +389,10 @@ struct WinThread {
                     strec<S, 9>(A_.M + vM, e, mr);
                 }
             } else {
-                mr = mx;
+                mr = stage_get<RawRec<S, 9>>(lds, NW3).dec();
             }
 #pragma unroll
             for (int n = 0; n < 9; n++) sys[n] = mr.v[n];
-            // everything slot 0 reads from memory has been used: request the next step's
-            load_slot0(wa, tb, s + 1, hk);
         } else {
 #pragma unroll
             for (int n = 0; n < 9; n++) sys[n] = H2[q][n];
@@ -386,58 +430,94 @@ struct WinThread {
     }
 
     template <int q>
-    FR3D_HD void slots_down(const WinArgs<S> &wa, const Tab &tb, int s, const WinLds<V, W> &lds, int pp,
-                            V (&Onew)[W + 1][3], V (&Hnew)[W][9], const Hook &hk)
+    FR3D_HD void slots_up(const WinArgs<S> &wa, const Tab &tb, int s, Lds &lds, int pp, V (&Onew)[W + 1][3],
+                          V (&Hnew)[W][9], const Hook &hk)
     {
         slot<q>(wa, tb, s, lds, pp, Onew, Hnew, hk);
-        if constexpr (q >= 1) slots_down<q - 1>(wa, tb, s, lds, pp, Onew, Hnew, hk);
+        if constexpr (q + 1 < W) slots_up<q + 1>(wa, tb, s, lds, pp, Onew, Hnew, hk);
     }
 
-    // step s: the imports of step s+1 go out first (they have the whole step to arrive), then every slot, last to
-    // first, reading the LDS image of step s-1; at the end the state moves on one step -- where a line is taken over
-    // from another tile (slot qa / qb of this thread) its history and its system are REPLACED by the imports there, so
-    // the slots never look at them -- and the outputs and neighbour imports are published in LDS.  The caller puts a
-    // barrier behind it.
-    FR3D_HD void step(const WinArgs<S> &wa, const Tab &tb, int s, WinLds<V, W> &lds, const Hook &hk)
+    // step s: everything step s+1 needs from HBM is requested first (step-local values: they have the whole step to
+    // arrive), then every slot reads the LDS image of step s-1 and computes; at the bottom the outputs are published,
+    // the requests are parked in this thread's staging / import entries, and the state moves on one step -- where a
+    // line is taken over from another tile (slot qa / qb of this thread) its history and its system are REPLACED by the
+    // imports there, so the slots never look at them.  The caller puts a barrier behind it.
+    FR3D_HD void step(const WinArgs<S> &wa, const Tab &tb, int s, Lds &lds, const Hook &hk)
     {
-        if (qa < W) load_special<0>(wa, tb, qa, s + 1, hk);
-        if (qb < W) load_special<1>(wa, tb, qb, s + 1, hk);
-        load_top(wa, tb, s + 1, hk);
         V Onew[W + 1][3], Hnew[W][9];
+        {
+            const Rec<S, 3> l = stage_get<RawRec<S, 3>>(lds, 0).dec();  // the loader's output of this step
 #pragma unroll
-        for (int c = 0; c < 3; c++) Onew[0][c] = Lnext.v[c];  // the loader's output of this step
-        load_loader(wa, tb, s + 1, hk);
+            for (int c = 0; c < 3; c++) Onew[0][c] = l.v[c];
+        }
+        // slot 0 (the psi update: the step's register peak) first, the requests behind it: they have the other slots'
+        // arithmetic to arrive and do not sit in registers during the peak
+        slot<0>(wa, tb, s, lds, (s - 1) & 1, Onew, Hnew, hk);
+        Req rq;
+        request_own(wa, tb, s + 1, rq, hk);
+        if (qa < W) request_special<0>(wa, tb, qa, s + 1, rq.NBa, rq.SWa, rq.SXa, rq.SMa, hk);
+        if (qb < W) request_special<1>(wa, tb, qb, s + 1, rq.NBb, rq.SWb, rq.SXb, rq.SMb, hk);
+        if (a == WIN_BK - 1 || b == WIN_BJ - 1) request_top(wa, tb, s + 1, rq, hk);
         WIN_SCHED_FENCE();
-        slots_down<W - 1>(wa, tb, s, lds, (s - 1) & 1, Onew, Hnew, hk);
+        if constexpr (W > 1) slots_up<1>(wa, tb, s, lds, (s - 1) & 1, Onew, Hnew, hk);
         const int pc = s & 1;
 #pragma unroll
         for (int q = 0; q <= W; q++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                lds.O[pc][q][c][tid] = Onew[q][c];
-                Om2[q][c] = Om1[q][c];
-                Om1[q][c] = Onew[q][c];
+            for (int c = 0; c < 3; c++) lds.O[pc][q][c][tid] = Onew[q][c];
+        // park the requests
+        stage_put(lds, 0, rq.L);
+        if constexpr (BUILD) {
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                stage_put(lds, NW3 + c * (NW12 + NWT), rq.fr[c]);
+                stage_put(lds, NW3 + c * (NW12 + NWT) + NW12, rq.wt[c]);
             }
-        // taken-over lines: slot q's history of the next step is the import (voxel i+1 now, its own old value then)
-#pragma unroll
-        for (int q = 1; q < W; q++) {
-            const bool ia = q == qa, ib = q == qb && qa != qb;
-#pragma unroll
-            for (int c = 0; c < 3; c++) Om1[q][c] = sel(ia, SWa.v[c], sel(ib, SWb.v[c], Om1[q][c]));
-#pragma unroll
-            for (int n = 0; n < 9; n++) {
-                H2[q][n] = sel(ia, SMa.v[n], sel(ib, SMb.v[n], H1[q][n]));
-                H1[q][n] = Hnew[q][n];
-            }
+            stage_put(lds, NW3 + C * (NW12 + NWT), rq.lr);
+        } else {
+            stage_put(lds, NW3, rq.mx);
         }
+        Rec<S, 3> swa_, swb_;
+        Rec<S, 9> sma_, smb_;
+        if (qa < W) {
+            const Rec<S, 3> nb = rq.NBa.dec(), sx = rq.SXa.dec();
+            swa_ = rq.SWa.dec(); sma_ = rq.SMa.dec();
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            lds.imp[WIN_IMP_ZM][c][tid] = NBa.v[c];
-            lds.imp[WIN_IMP_YM][c][tid] = NBb.v[c];
-            lds.imp[WIN_IMP_YP_SW][c][tid] = SXa.v[c];
-            lds.imp[WIN_IMP_ZP_SW][c][tid] = SXb.v[c];
-            lds.imp[WIN_IMP_ZP_TOP][c][tid] = TOPa.v[c];
-            lds.imp[WIN_IMP_YP_TOP][c][tid] = TOPb.v[c];
+            for (int c = 0; c < 3; c++) { lds.imp_zm[ixa][c] = nb.v[c]; lds.imp_ypsw[ixa][c] = sx.v[c]; }
+        }
+        if (qb < W) {
+            const Rec<S, 3> nb = rq.NBb.dec(), sx = rq.SXb.dec();
+            swb_ = rq.SWb.dec(); smb_ = rq.SMb.dec();
+#pragma unroll
+            for (int c = 0; c < 3; c++) { lds.imp_ym[ixb][c] = nb.v[c]; lds.imp_zpsw[ixb][c] = sx.v[c]; }
+        }
+        if (a == WIN_BK - 1) {
+            const Rec<S, 3> t = rq.TOPa.dec();
+#pragma unroll
+            for (int c = 0; c < 3; c++) lds.imp_zptop[b][c] = t.v[c];
+        }
+        if (b == WIN_BJ - 1) {
+            const Rec<S, 3> t = rq.TOPb.dec();
+#pragma unroll
+            for (int c = 0; c < 3; c++) lds.imp_yptop[a][c] = t.v[c];
+        }
+        // the state moves on; taken-over lines: slot q's history of the next step is the import (voxel i+1 now, its own
+        // old value one step later), its system the imported record
+#pragma unroll
+        for (int q = 0; q < W; q++) {
+            const bool ia = q >= 1 && q == qa, ib = q >= 1 && q == qb && qa != qb;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                Om2[q][c] = Om1[q][c];
+                Om1[q][c] = sel(ia, swa_.v[c], sel(ib, swb_.v[c], Onew[q][c]));
+            }
+            if (q >= 1) {
+#pragma unroll
+                for (int n = 0; n < 9; n++) {
+                    H2[q][n] = sel(ia, sma_.v[n], sel(ib, smb_.v[n], H1[q][n]));
+                    H1[q][n] = Hnew[q][n];
+                }
+            }
         }
     }
 };

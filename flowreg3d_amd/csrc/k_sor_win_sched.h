@@ -40,6 +40,7 @@ static inline std::vector<WinWindow> make_windows(int iterations, int update_lag
 struct WinSchedHost {
     std::vector<WinTile> tiles;     // all launches back to back
     std::vector<int> first, count;  // per launch
+    std::vector<int> nbuild;        // per launch: tiles of windows that build their system (they come first)
     std::vector<int> win;           // per tile: window index (emulator's version checks)
     std::vector<WinWindow> windows;
     int nwin = 0;
@@ -61,10 +62,13 @@ static inline WinSchedHost make_win_schedule(int Z, int Y, int iterations, int u
     const int nl = dmax + WIN_DLAG * (sc.nwin - 1) + 1;
     for (int l = 0; l < nl; l++) {
         sc.first.push_back((int)sc.tiles.size());
+        for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) sc.nbuild.push_back((int)sc.tiles.size() - sc.first.back());
         for (int b = 0; b < sc.nwin; b++) {
             const int D = l - WIN_DLAG * b;
             if (D < 0) break;
             const WinWindow &x = ww[b];
+            if (x.build != (pass == 0)) continue;
             const int Kn = ntile(Z, x.n, WIN_BK), Jn = ntile(Y, x.n, WIN_BJ);
             for (int K = std::max(0, D - (Jn - 1)); K <= std::min(D, Kn - 1); K++) {
                 WinTile t;
@@ -75,6 +79,7 @@ static inline WinSchedHost make_win_schedule(int Z, int Y, int iterations, int u
                 sc.tiles.push_back(t);
                 sc.win.push_back(b);
             }
+        }
         }
         sc.count.push_back((int)sc.tiles.size() - sc.first.back());
     }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <type_traits>
 #include <vector>
 
 #include "k_sor_win_sched.h"
@@ -126,24 +127,34 @@ static int run(int Z, int Y, int X, int T, int lag, unsigned seed)
     const WinSchedHost sc = make_win_schedule(Z, Y, T, lag, W);
     Shadow sh[2 + W - 1];
     for (auto &s : sh) s.init((size_t)total);
-    using Th = WinThread<R, S, C, W, WinTabPtr, EmuHook>;
-    std::vector<Th> th(WIN_NT);
-    static WinLds<V, W> lds;
     long long wg = 0, steps = 0;
+    auto run_tile = [&](auto build_tag, const WinTile &tl, int win, int l, int n) {
+        constexpr bool BUILD = decltype(build_tag)::value;
+        using Th = WinThread<R, S, C, W, BUILD, WinTabPtr, EmuHook>;
+        static std::vector<Th> th(WIN_NT);
+        static typename Th::Lds lds;
+        EmuHook hk{sh, l, n};
+        int s0, s1;
+        Th::step_range(sk, tl, s0, s1);
+        memset(&lds, 0xff, sizeof(lds));  // stale LDS content must not matter
+        for (int tid = 0; tid < WIN_NT; tid++) {
+            th[tid].init(wa, tl, 0, tid, win, sc.windows[win].win_build);
+            th[tid].init_lds(lds);
+        }
+        for (int s = s0 - WIN_LEAD; s <= s1; s++) {
+            for (int tid = 0; tid < WIN_NT; tid++) th[tid].step(wa, tb, s, lds, hk);
+            steps++;
+        }
+        wg++;
+    };
     for (size_t l = 0; l < sc.first.size(); l++) {
         for (int n = 0; n < sc.count[l]; n++) {
             const WinTile &tl = sc.tiles[sc.first[l] + n];
             const int win = sc.win[sc.first[l] + n];
-            EmuHook hk{sh, (int)l, n};
-            int s0, s1;
-            Th::step_range(sk, tl, s0, s1);
-            memset(&lds, 0, sizeof(lds));
-            for (int tid = 0; tid < WIN_NT; tid++) th[tid].init(wa, tl, 0, tid, win, sc.windows[win].win_build);
-            for (int s = s0 - WIN_LEAD; s <= s1; s++) {
-                for (int tid = 0; tid < WIN_NT; tid++) th[tid].step(wa, tb, s, lds, hk);
-                steps++;
-            }
-            wg++;
+            const bool build = (tl.info >> 8) & 1;
+            if (build != (n < sc.nbuild[l])) { printf("  schedule: build tiles must come first\n"); g_errors++; }
+            if (build) run_tile(std::true_type{}, tl, win, (int)l, n);
+            else run_tile(std::false_type{}, tl, win, (int)l, n);
         }
     }
     long long bad = 0;
