@@ -14,9 +14,13 @@ Prints ONE JSON line on rank 0 (schema in the task contract) with `roofline` for
 kernel (HIP events on the engine's stream) and `cpu_baseline` (the C oracle on a bounded sample, one
 core and all cores).  At N = 1 the default run adds two legs to the same line, after the timed region of
 the headline workload: `host_path` (NumPy arrays in, NumPy arrays out through fr3d_process_batch: the
-PCIe-inclusive rate of the drop-in entry, never `value`) and `cfg3` (the 512^3 six-level configuration,
-4 timed steps at lock-step batch 4, with its own `roofline`) and `a_smooth_0.5` (the psi_smooth solver path on
-the cfg2 geometry); `--no-extras` skips them.  The timed region runs the library's default of two engine lanes; `one_lane`
+PCIe-inclusive rate of the drop-in entry, never `value`), `pipeline` (the whole drop-in driver compensate_arr_3D:
+preprocessing, w_init bootstrap, executor, statistics -- host arrays and device sink), `single_pair` (one
+get_displacement call, the reference's API unit, at 256^3 and 512^3), `cfg3` (the 512^3 six-level configuration on
+SURVEY 8d's input recipe, 4 timed steps at lock-step batch 4, with its own `roofline`), `cfg5` (two channels) and
+`a_smooth_0.5` (the psi_smooth solver path on the cfg2 geometry); `--no-extras` skips them.
+`roofline.frac` prices the sweep on SURVEY 8d's contract bytes (4 B per value: 76 B per voxel update for one channel),
+whatever the storage format; `frac_on_storage_basis` prices the same time on the mode's own format.  The timed region runs the library's default of two engine lanes; `one_lane`
 is the profiled one-lane pass right after it, on which `roofline` is measured (--lanes 1: the timed region itself).
 """
 import argparse
@@ -37,10 +41,16 @@ WORKLOADS = {
     "cfg1": (32, 64, 64, 2, "64x64x32 pair, 3-level pyramid"),
     "cfg2": (256, 256, 256, 4, "256^3 single-channel fp32, 5-level pyramid"),
     "cfg3": (512, 512, 512, 5, "512^3 single-channel fp32, 6-level pyramid"),
+    # BASELINE config 5's geometry with the 13-solve schedule its parity fixture uses (tests/golden/fullsize_cfg5.npz)
+    "cfg5": (256, 512, 512, 12, "256x512x512 two-channel fp32, 13-level pyramid"),
 }
+CHANNELS = {"cfg5": 2}
 # cfg4 = cfg2 on a 64-timepoint series sharded over N GPUs: `--workload cfg2 --gpus N --steps 8`.
-# cfg5 (512x512x256, two channels) is a parity case (tests/test_gpu_e2e.py, tools/run_cfg5.py), not a bench line.
+# cfg5 (512x512x256, two channels) is a parity case (tests/test_gpu_fullsize_parity.py); the default run times it as an extra leg.
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+_REF_CACHE = {}  # (Z, Y, X, recipe) -> reference volume: the 512^3 texture costs half a minute of host time, once per process
 
 
 def solver_kwargs(levels, a_smooth=1.0):
@@ -152,7 +162,24 @@ def cpu_baseline(workload, sample_edge):
             "fullsize_1core_measured": "one whole 256^3 volume (flow solve only) measured 206 s on one core of a GPU host "
                                        "(round 1) and 414-460 s in the 8-core build container (tests/golden/fullsize_cfg2*.npz "
                                        "metadata): the voxel-count scaling of the sample flatters the CPU by ~15 %",
+            "fullsize_oracle_seconds_1core": fullsize_cpu_seconds(),
             "sample_volumes_per_sec_all_cores": rate_all, "host_cpus": os.cpu_count()}
+
+
+def fullsize_cpu_seconds():
+    """Seconds one core needed for ONE whole volume's flow solve at full size: the CPU-oracle runs that produced the
+    parity fixtures (tests/golden/fullsize_*.npz metadata; 8-core build container, one core per run).  Measured, not
+    scaled: 512^3 costs ~2700-3700 s, i.e. 2.7e-4 .. 3.7e-4 volumes/s on one core."""
+    out = {}
+    for case in ("cfg2_recipe", "cfg3", "cfg3_recipe", "cfg5"):
+        try:
+            z = np.load(os.path.join(ROOT, "tests", "golden", f"fullsize_{case}.npz"))
+            meta = json.loads(bytes(z["meta"]).decode())
+            out[case] = {"shape_zyx": meta["shape_zyx"], "channels": meta["channels"],
+                         "seconds": round(float(meta["oracle_seconds_1core"]), 1)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return out
 
 
 SOLVER_NAMES = ("fp32 storage, fp32 update arithmetic", "fp32 storage, fp64 update arithmetic",
@@ -172,6 +199,10 @@ def parity_record(workload, mode, recipe_inputs):
         return None, "profiles/parity_fullsize.json missing"
     for case in ((workload + "_recipe", workload) if recipe_inputs else (workload, workload + "_recipe")):
         e = rec.get(f"{case}/mode{mode}")
+        if e and workload == "cfg5":
+            return e["lattice_mean_epe"], (f"profiles/parity_fullsize.json[{case}/mode{mode}]: lattice mean EPE vs the CPU oracle on the "
+                                           "expansion + rotation pair of tests/golden/fullsize_cfg5.npz; this run TIMES a "
+                                           "translated stand-in texture of the same geometry")
         if e:
             same = case.endswith("_recipe") == bool(recipe_inputs)
             return e["lattice_mean_epe"], (f"profiles/parity_fullsize.json[{case}/mode{mode}]: lattice mean EPE vs the CPU oracle, "
@@ -211,26 +242,31 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
     lib.fr3d_set_lanes(lanes)
     from flowreg3d_amd.synthetic import fast_pair, flow_gt, texture
     Z, Y, X, levels, desc = WORKLOADS[workload]
+    nch = CHANNELS.get(workload, 1)
     nv = Z * Y * X
     T = K + W
-    params = _lib.make_params(n_channels=1, solver_fp64=None if solver_fp64 < 0 else solver_fp64,
+    params = _lib.make_params(n_channels=nch, solver_fp64=None if solver_fp64 < 0 else solver_fp64,
                               **solver_kwargs(levels, a_smooth))
-    mode = resolved_mode(solver_fp64, nv, 1, a_smooth)
+    mode = resolved_mode(solver_fp64, nv, nch, a_smooth)
 
     def reference_volume():
-        # texture(): blurred noise + blobs; fast_pair's O(N) stand-in where the 512^3 blur would
-        # cost a minute of host time inside the default run
-        return fast_pair((Z, Y, X))[0] if fast_inputs else texture((Z, Y, X), seed=1234)
+        # texture(): blurred noise + blobs (SURVEY 8d's recipe, the inputs the parity records were measured on);
+        # fast_inputs: fast_pair's O(N) stand-in
+        key = (Z, Y, X, nch, not fast_inputs)
+        if key not in _REF_CACHE:
+            chans = [fast_pair((Z, Y, X), seed=1234 + c)[0] if fast_inputs else texture((Z, Y, X), seed=1234 + c) for c in range(nch)]
+            _REF_CACHE[key] = chans[0] if nch == 1 else np.ascontiguousarray(np.stack(chans, -1))
+        return _REF_CACHE[key]
 
     # ---- fixed reference: generated on rank 0, broadcast over RCCL/xGMI -----------------------
-    ref_dev = DevArray(lib, (Z, Y, X, 1))
+    ref_dev = DevArray(lib, (Z, Y, X, nch))
     ref_t = None
     bcast_ms = None
     if world > 1:
         import torch
-        ref_t = torch.empty((Z, Y, X), dtype=torch.float32, device=f"cuda:{dev_index}")
+        ref_t = torch.empty((Z, Y, X, nch), dtype=torch.float32, device=f"cuda:{dev_index}")
         if rank == 0:
-            ref_t.copy_(torch.from_numpy(reference_volume()))
+            ref_t.copy_(torch.from_numpy(reference_volume().reshape(Z, Y, X, nch)))
         torch.cuda.synchronize()
         dist.barrier()
         t_b = time.perf_counter()
@@ -243,21 +279,21 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
         fixed_ptr = ref_dev.ptr
 
     # ---- this rank's shard of the time series: moving_t = warp(fixed, -flow_gt * s_t) on the GPU --
-    batch = DevArray(lib, (T, Z, Y, X, 1))
+    batch = DevArray(lib, (T, Z, Y, X, nch))
     flows = DevArray(lib, (T, Z, Y, X, 3))
-    regs = DevArray(lib, (T, Z, Y, X, 1))
+    regs = DevArray(lib, (T, Z, Y, X, nch))
     gflow = DevArray(lib, (Z, Y, X, 3))
     for i in range(T):
         t_global = rank + world * i
         s = np.sin(2.0 * np.pi * (t_global + 1) / 64.0) + 0.35
         gflow.upload(-flow_gt((Z, Y, X), scale=float(s)))
-        _lib.check(lib.fr3d_warp_dev(fixed_ptr, _lib.F32, gflow.ptr, _lib.F32, fixed_ptr, Z, Y, X, 1, 3,
-                                     batch.ptr + i * nv * 4))
+        _lib.check(lib.fr3d_warp_dev(fixed_ptr, _lib.F32, gflow.ptr, _lib.F32, fixed_ptr, Z, Y, X, nch, 3,
+                                     batch.ptr + i * nv * 4 * nch))
     gflow.free()
 
     # default lock-step batch: 8 at 256^3, 4 at 512^3 (the compact solver slabs of a 512^3 volume take 16 GB with
     # fp32 storage, 33 GB with fp64 storage; batch 8 fits too and runs at the same rate per volume)
-    batch_vols = max(1, min(K, batch_arg if batch_arg > 0 else (4 if workload == "cfg3" else 8)))
+    batch_vols = max(1, min(K, batch_arg if batch_arg > 0 else (4 if nv > (1 << 25) else 8)))
     lib.fr3d_set_batch(batch_vols)  # warm-up and timed run use the same lock-step batch / workspace
 
     def run(first, count, prof):
@@ -265,8 +301,8 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
         if prof:
             lib.fr3d_prof_reset()
         _lib.check(lib.fr3d_process_batch_dev(
-            C.byref(params), batch.ptr + first * nv * 4, batch.ptr + first * nv * 4, fixed_ptr, fixed_ptr,
-            None, None, count, Z, Y, X, 1, 3, flows.ptr + first * nv * 12, regs.ptr + first * nv * 4,
+            C.byref(params), batch.ptr + first * nv * 4 * nch, batch.ptr + first * nv * 4 * nch, fixed_ptr, fixed_ptr,
+            None, None, count, Z, Y, X, nch, 3, flows.ptr + first * nv * 12, regs.ptr + first * nv * 4 * nch,
             C.cast(None, _lib.PROGRESS_FN), None))
 
     def barrier():
@@ -334,7 +370,7 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 pj = json.load(fh)
-            pmc = pj.get(f"{workload}/mode{mode}") if a_smooth == 1.0 else None
+            pmc = pj.get(f"{workload}/mode{mode}") if a_smooth == 1.0 else None  # (single-channel records; none for cfg5)
             if pmc and pj.get("_sweep_source_hash") != sweep_source_hash():
                 traffic_source = ("profiles/pmc_traffic.json was taken on other sweep-kernel sources "
                                   f"({pj.get('_sweep_source_hash')} != {sweep_source_hash()}): not quoted")
@@ -345,26 +381,36 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
                                  "updates per launch -- separate rocprofv3 --pmc passes, not measured by this run"
         except (OSError, ValueError, KeyError):
             traffic = None
-        channels = 1
-        basis = sor["algo_bytes"] / max(sor["units"], 1)
+        channels = nch
+        storage_basis = sor["algo_bytes"] / max(sor["units"], 1)
         vals = 10 * channels + (9 if a_smooth == 1.0 else 17)
-        # the same time priced on SURVEY 8d's fp32 figure (4 B per value: 76 B per update for C = 1, a_smooth = 1), so that
-        # legs with different storage formats stay comparable
-        frac_fp32_basis = (4.0 * vals * sor["units"] / (sor["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if sor["ms"] > 0 else 0.0
+        # SURVEY 8d prices the sweep at 4 B per value (76 B per voxel update for C = 1, a_smooth = 1) whatever the storage
+        # format: `frac` is on that basis, so that rounds and storage formats compare; the storage-format figure is beside it
+        contract_basis = 4.0 * vals
+        secs = sor["ms"] * 1e-3
+        achieved = contract_basis * sor["units"] / secs / 1e9 if secs > 0 else 0.0
+        per_launch = sor["units"] / max(sor["launches"], 1)
         res["roofline"] = {"bound": "hbm",
                            "kernel": "k_sor_step (SOR hyperplane sweep)" if a_smooth == 1.0 else
                                      "k_smooth_step + k_smooth_psi (psi_smooth SOR sweep, a_smooth != 1)",
-                           "algo_bytes_per_update": basis,
-                           "basis": f"{vals} values per voxel update ({'9 J + w psi + 3 L + 3 d read, 3 d written' if a_smooth == 1.0 else '9 J + w psi + 3 u + 3 d + psi_s read, 3 d written; psi_s: 3 u + 3 d read, 1 written'}) "
-                                    f"x {STORAGE_BYTES[mode]:.3g} B per value in this mode's storage format",
+                           "algo_bytes_per_update": contract_basis,
+                           "basis": f"SURVEY 8d: {vals} values per voxel update ({'9 J + w psi + 3 L + 3 d read, 3 d written' if a_smooth == 1.0 else '9 J + w psi + 3 u + 3 d + psi_s read, 3 d written; psi_s: 3 u + 3 d read, 1 written'}) "
+                                    "x 4 B (the fp32 figure of the contract, independent of this mode's storage format)",
                            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "frac_on_fp32_basis": frac_fp32_basis,
+                           "frac": achieved / HBM_PEAK_GBS,
+                           "storage_bytes_per_update": storage_basis,
+                           "storage_basis": f"{vals} values x {STORAGE_BYTES[mode]:.3g} B per value in this mode's storage format",
+                           "achieved_on_storage_basis": storage_basis * sor["units"] / secs / 1e9 if secs > 0 else 0.0,
+                           "frac_on_storage_basis": (storage_basis * sor["units"] / secs / 1e9 / HBM_PEAK_GBS) if secs > 0 else 0.0,
                            "traffic": traffic, "traffic_source": traffic_source,
-                           "algo_bytes_per_launch": sor["algo_bytes"] / max(sor["launches"], 1),
+                           "traffic_over_algorithmic": None if traffic is None else traffic / (contract_basis * per_launch),
+                           "algo_bytes_per_launch": contract_basis * per_launch,
                            "avg_launch_us": 1e3 * sor["ms"] / max(sor["launches"], 1),
                            "launches": sor["launches"],
+                           "sor_ms_per_step": sor["ms"] / K,
                            "measured_on": "the timed region (one engine lane)" if lanes == 1 else
-                                          "a profiled one-lane pass of the same K steps directly after the timed region (see `one_lane`); "
+                                          "a profiled one-lane pass of the same K steps directly after the timed region (see `one_lane`: "
+                                          "sor_ms_per_step is a part of one_lane.ms_per_step, not of the two-lane ms_per_step); "
                                           "the timed region runs two lanes, whose kernels overlap in time"}
         res["kernel_ms_per_step"] = {k: round(v["ms"] / K, 3) for k, v in stats.items()}
         # the other stages of the path against the same HBM roofline, algorithmic bytes as in
@@ -372,7 +418,7 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
         res["roofline_stages"] = {k: {"achieved": round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "unit": "GB/s",
                                       "frac": round(v["algo_bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                                   for k, v in stats.items()
-                                  if k in ("warp", "prefilter", "tensor", "resize", "median") and v["ms"] > 0}
+                                  if k in ("warp", "prefilter", "tensor", "resize", "median", "preproc") and v["ms"] > 0}
     for a in (batch, flows, regs, ref_dev):
         a.free()
     del ref_t
@@ -404,6 +450,137 @@ def host_path(workload, n_vol, solver_fp64):
     return {"value": n_vol / best, "unit": "volumes/sec", "volumes": n_vol,
             "what": f"{workload}: HipExecutor3D.process_batch on NumPy arrays ({batch.nbytes >> 20} MiB in x2, "
                     f"{(reg.nbytes + flows.nbytes) >> 20} MiB out, pageable memory), second of two calls"}
+
+
+def make_series(lib, _lib, shape, n_vol):
+    """n_vol moving volumes of the synthetic series (device warp of SURVEY 8d's texture) as one host array, + the reference"""
+    from flowreg3d_amd.synthetic import flow_gt, texture
+    Z, Y, X = shape
+    nv = Z * Y * X
+    key = (Z, Y, X, 1, True)
+    if key not in _REF_CACHE:
+        _REF_CACHE[key] = texture((Z, Y, X), seed=1234)
+    ref = _REF_CACHE[key]
+    ref_dev = DevArray(lib, (Z, Y, X, 1)).upload(ref)
+    gflow = DevArray(lib, (Z, Y, X, 3))
+    one = DevArray(lib, (Z, Y, X, 1))
+    series = np.empty((n_vol, Z, Y, X, 1), np.float32)
+    for t in range(n_vol):
+        s = np.sin(2.0 * np.pi * (t + 1) / 64.0) + 0.35
+        gflow.upload(-flow_gt((Z, Y, X), scale=float(s)))
+        _lib.check(lib.fr3d_warp_dev(ref_dev.ptr, _lib.F32, gflow.ptr, _lib.F32, ref_dev.ptr, Z, Y, X, 1, 3, one.ptr))
+        series[t] = one.download()
+    for a in (ref_dev, gflow, one):
+        a.free()
+    return series, ref
+
+
+def pipeline_leg(lib, _lib, n_vol=16, buffer_size=8):
+    """The whole drop-in driver (flowreg3d_amd.pipeline.compensate_arr_3D: the reference's compensate_arr_3D ->
+    BatchMotionCorrector.run, motion_correction/compensate_recording_3D.py:229-254,431-555): preprocessing (normalise +
+    Gaussian, fp64), the w_init bootstrap (the first batch is solved twice: from zero, then from the mean flow), the
+    executor, the w_init roll, statistics.  Host arrays in and out, then the device-resident sink."""
+    from flowreg3d_amd.pipeline import BatchMotionCorrectorHip, Options, compensate_arr_3D
+    Z, Y, X, levels, _ = WORKLOADS["cfg2"]
+    series, ref = make_series(lib, _lib, (Z, Y, X), n_vol)
+    opt = Options(alpha=(0.25, 0.25, 0.25), weight=[1.0], levels=levels, min_level=0, eta=0.8, update_lag=5, iterations=100,
+                  a_smooth=1.0, a_data=0.45, buffer_size=buffer_size, output_typename="single")
+    solves = n_vol + min(22, buffer_size, n_vol)  # every volume once + the bootstrap pass over the first batch
+    lib.fr3d_prof_enable(0)
+    t0 = time.perf_counter()
+    reg, w = compensate_arr_3D(series, ref[..., None], opt)
+    t_host = time.perf_counter() - t0
+    del reg, w
+    # device sink, with the stage brackets on (one lane) for the preprocessing kernel's share
+    lib.fr3d_prof_enable(1)
+    lib.fr3d_prof_reset()
+    t0 = time.perf_counter()
+    sink = BatchMotionCorrectorHip(opt).run(series, ref[..., None], sink="device")
+    lib.fr3d_sync()
+    t_dev_prof = time.perf_counter() - t0
+    stats = _lib.prof_get()
+    lib.fr3d_prof_enable(0)
+    sink.free()
+    t0 = time.perf_counter()
+    sink = BatchMotionCorrectorHip(opt).run(series, ref[..., None], sink="device")
+    lib.fr3d_sync()
+    t_dev = time.perf_counter() - t0
+    sink.free()
+    pre = stats["preproc"]
+    nvox = float(Z) * Y * X
+    # per volume the reference's preprocessing reads the raw volume and writes the processed one once per separable
+    # pass; algorithmic bytes as for the resampler (SURVEY 8d): (N_in + N_out) values per pass, fp64 between the passes
+    return {"workload": f"cfg2 geometry, {n_vol} volumes of the synthetic series, buffer_size {buffer_size}: "
+                        f"{solves} flow solves (bootstrap pass over the first batch + every volume)",
+            "value": n_vol / t_host, "unit": "volumes/sec", "seconds": t_host,
+            "solves_per_sec": solves / t_host,
+            "what": "compensate_arr_3D on NumPy arrays (float32 series in, float32 registered + flows out; pageable memory)",
+            "device_sink": {"value": n_vol / t_dev, "unit": "volumes/sec", "seconds": t_dev, "solves_per_sec": solves / t_dev,
+                            "what": "BatchMotionCorrectorHip.run(sink='device'): batches uploaded once, everything else resident in HBM",
+                            "seconds_with_stage_brackets_one_lane": t_dev_prof},
+            "preproc_ms_per_volume": pre["ms"] / max(n_vol + 1, 1),
+            "preproc": {"ms": pre["ms"], "launches": pre["launches"], "volumes": n_vol + 1,
+                        "achieved": round(pre["algo_bytes"] / (pre["ms"] * 1e-3) / 1e9, 1) if pre["ms"] > 0 else None,
+                        "unit": "GB/s", "frac": round(pre["algo_bytes"] / (pre["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pre["ms"] > 0 else None,
+                        "basis": "per separable pass one read and one write of the volume in the pass's own types "
+                                 f"({nvox:.0f} voxels per volume; the reference volume is preprocessed once too)"},
+            "kernel_ms_per_volume_device_sink": {k: round(v["ms"] / n_vol, 3) for k, v in stats.items()}}
+
+
+def single_pair_leg(lib, _lib, workload, solver_fp64):
+    """One get_displacement call -- the reference's API unit (core/optical_flow_3d.py:319) -- on device-resident
+    volumes, batch of one; and the time to the FIRST result of a lock-step batch beside it (256^3)."""
+    from flowreg3d_amd.synthetic import flow_gt, texture
+    Z, Y, X, levels, desc = WORKLOADS[workload]
+    nv = Z * Y * X
+    key = (Z, Y, X, 1, True)
+    if key not in _REF_CACHE:
+        _REF_CACHE[key] = texture((Z, Y, X), seed=1234)
+    fixed = DevArray(lib, (Z, Y, X, 1)).upload(_REF_CACHE[key])
+    gflow = DevArray(lib, (Z, Y, X, 3)).upload(-flow_gt((Z, Y, X)))
+    moving = DevArray(lib, (Z, Y, X, 1))
+    flow = DevArray(lib, (Z, Y, X, 3))
+    _lib.check(lib.fr3d_warp_dev(fixed.ptr, _lib.F32, gflow.ptr, _lib.F32, fixed.ptr, Z, Y, X, 1, 3, moving.ptr))
+    params = _lib.make_params(n_channels=1, solver_fp64=None if solver_fp64 < 0 else solver_fp64, **solver_kwargs(levels))
+    times = []
+    for _ in range(4):  # the first call allocates the workspace
+        lib.fr3d_sync()
+        t0 = time.perf_counter()
+        _lib.check(lib.fr3d_get_displacement_dev(C.byref(params), fixed.ptr, moving.ptr, Z, Y, X, 1, None, None, flow.ptr))
+        lib.fr3d_sync()
+        times.append(time.perf_counter() - t0)
+    out = {"workload": f"{workload}: {desc}; one fr3d_get_displacement_dev call (flow solve only, no final warp)",
+           "seconds": min(times[1:]), "value": 1.0 / min(times[1:]), "unit": "volumes/sec",
+           "solver": SOLVER_NAMES[int(lib.fr3d_last_solver_mode())], "calls_s": [round(t, 4) for t in times]}
+    if nv <= (1 << 24):
+        # latency of the first result when 8 volumes are solved in lock step on one lane (fr3d_set_batch lowers it)
+        n = 8
+        batch = DevArray(lib, (n, Z, Y, X, 1))
+        for t in range(n):
+            _lib.check(lib.fr3d_warp_dev(fixed.ptr, _lib.F32, gflow.ptr, _lib.F32, fixed.ptr, Z, Y, X, 1, 3, batch.ptr + t * nv * 4))
+        flows = DevArray(lib, (n, Z, Y, X, 3))
+        regs = DevArray(lib, (n, Z, Y, X, 1))
+        stamps = []
+        cb = _lib.PROGRESS_FN(lambda k, _u: stamps.append(time.perf_counter()))
+        lat = {}
+        for lanes in (1, 2):
+            lib.fr3d_set_lanes(lanes)
+            lib.fr3d_set_batch(n)
+            for rep in range(2):
+                del stamps[:]
+                t0 = time.perf_counter()
+                _lib.check(lib.fr3d_process_batch_dev(C.byref(params), batch.ptr, batch.ptr, fixed.ptr, fixed.ptr, None, None, n,
+                                                      Z, Y, X, 1, 3, flows.ptr, regs.ptr, cb, None))
+                lib.fr3d_sync()
+                t_all = time.perf_counter() - t0
+            lat[f"lanes{lanes}"] = {"first_result_s": round(stamps[0] - t0, 4) if stamps else None, "all_8_s": round(t_all, 4)}
+        lib.fr3d_set_lanes(2)
+        out["lockstep_batch_of_8"] = lat
+        for a in (batch, flows, regs):
+            a.free()
+    for a in (fixed, gflow, moving, flow):
+        a.free()
+    return out
 
 
 def main():
@@ -466,7 +643,7 @@ def main():
     lib = _lib.init(dev_index)
     K, W = args.steps, args.warmup
     m = measure(lib, _lib, args.workload, K, W, args.batch, args.condition, args.solver_fp64, rank, world, dist,
-                dev_index, fast_inputs=args.workload == "cfg3", a_smooth=args.a_smooth, lanes=args.lanes)
+                dev_index, fast_inputs=False, a_smooth=args.a_smooth, lanes=args.lanes)
 
     if rank == 0:
         elapsed = m["elapsed"]
@@ -513,16 +690,25 @@ def main():
         if world == 1 and not args.no_extras and args.workload == "cfg2":
             # (1) the host-array entry (PCIe both ways) -- reported beside `value`, never as `value`
             out["host_path"] = host_path("cfg2", 8, None if args.solver_fp64 < 0 else args.solver_fp64)
+            # (1b) the whole drop-in driver, and one get_displacement call (the reference's API unit)
+            out["pipeline"] = pipeline_leg(lib, _lib)
+            out["single_pair"] = {"cfg2": single_pair_leg(lib, _lib, "cfg2", args.solver_fp64)}
             # (2) the headline workload with fp32 solver storage (the mode SURVEY 8d's 76 B / update figure is defined on;
             # measured parity 8.6e-5 at 256^3: inside the bound, by a margin too thin for a default) and the 512^3
             # configuration the roofline target is stated on, in three storage modes: the library's choice (packed
             # 42-bit storage), fp32 storage (parity 1.5e-4, above the 1e-4 bound) and fp64 storage (reference-grade).
             # The workspace of the previous leg is released first.
             for key, wl, md, cond, nst in (("cfg2_fp32_storage", "cfg2", 1, 10.0, 8), ("cfg3", "cfg3", -1, 8.0, 4),
-                                           ("cfg3_fp32_storage", "cfg3", 1, 5.0, 4), ("cfg3_fp64_storage", "cfg3", 2, 5.0, 4)):
+                                           ("cfg3_fp32_storage", "cfg3", 1, 5.0, 4), ("cfg3_fp64_storage", "cfg3", 2, 5.0, 4),
+                                           ("cfg5", "cfg5", -1, 0.0, 2)):
                 _lib.shutdown()
                 lib = _lib.init(dev_index)
-                c3 = measure(lib, _lib, wl, nst, 1, 0, cond, md, 0, 1, None, dev_index, fast_inputs=wl == "cfg3", lanes=args.lanes)
+                if key == "cfg5":  # the 512^3 reference volume is still cached here
+                    out["single_pair"]["cfg3"] = single_pair_leg(lib, _lib, "cfg3", args.solver_fp64)
+                    _lib.shutdown()
+                    lib = _lib.init(dev_index)
+                # cfg5 on the O(N) stand-in texture per channel (its parity record is on make_pair's inputs: stated)
+                c3 = measure(lib, _lib, wl, nst, 1, 0, cond, md, 0, 1, None, dev_index, fast_inputs=wl == "cfg5", lanes=args.lanes)
                 out[key] = {"workload": f"{wl}: {c3['desc']}; same solver parameters", "value": nst / c3["elapsed"],
                             "unit": "volumes/sec", "steps": nst, "warmup": 1, "ms_per_step": 1e3 * c3["elapsed"] / nst,
                             "lockstep_batch": c3["batch_vols"], "untimed_conditioning_s": cond,

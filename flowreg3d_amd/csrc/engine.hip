@@ -1410,30 +1410,71 @@ static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int 
     for (int c = 0; c < C; c++) {
         const double *sg = sigma + 4 * c;            // sx, sy, sz, st
         const double ax_sigma[4] = {sg[3], sg[2], sg[1], sg[0]};  // array axes T, Z, Y, X
-        const double *cur = nullptr;                 // nullptr: still reading the caller's frames
-        double *dst = bufA;
-        int passes = 0;
+        // the passes scipy really runs: axes with sigma > 0 whose kernel has more than one tap (a kernel [1.0]
+        // multiplies by exactly 1)
+        struct Pass { int axis, radius; const double *w; };
+        Pass ps[4];
+        int np = 0;
         for (int axis = 0; axis < 4; axis++) {
             if (!(ax_sigma[axis] > 1e-15)) continue; // scipy skips these axes
             int radius;
             const double *dw = e.gauss_kernel(ax_sigma[axis], truncate, radius);
-            if (radius == 0 && cur) continue;        // kernel [1.0]: x*1.0 is x, nothing to do
-            if (!cur) launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, axis, dw, radius, dst);
-            else launch_gauss_pass<double>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, axis, dw, radius, dst);
-            cur = dst;
-            dst = (dst == bufA) ? bufB : bufA;
-            passes++;
+            if (radius == 0) continue;
+            ps[np++] = {axis, radius, dw};
         }
-        if (!cur) {  // no filtering at all: normalisation only (a radius-0 pass)
+        const double *cur = nullptr;                 // nullptr: still reading the caller's frames
+        double *dst = bufA;
+        int launches = 0;
+        double bytes = 0.0;
+        bool stored = false;
+        for (int p = 0; p < np; p++) {
+            const bool first = p == 0, last = p == np - 1;
+            bool done = false;
+            // fast kernels (radius 4): the last pass writes the caller's array itself
+            if (last) {
+                if (out_dtype == FR3D_F64)
+                    done = first ? launch_gauss_pass4<TIN, double, true>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, (double *)out, C, c)
+                                 : launch_gauss_pass4<double, double, false>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, (double *)out, C, c);
+                else
+                    done = first ? launch_gauss_pass4<TIN, float, true>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, (float *)out, C, c)
+                                 : launch_gauss_pass4<double, float, false>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, (float *)out, C, c);
+                if (done) {
+                    stored = true;
+                    bytes += (double)n * ((first ? sizeof(TIN) : 8.0) + (out_dtype == FR3D_F64 ? 8.0 : 4.0));
+                }
+            } else {
+                done = first ? launch_gauss_pass4<TIN, double, true>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, dst, 1, 0)
+                             : launch_gauss_pass4<double, double, false>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, dst, 1, 0);
+                if (done) bytes += (double)n * ((first ? sizeof(TIN) : 8.0) + 8.0);
+            }
+            if (!done) {  // any other radius / a very short axis: the general kernel
+                if (first) launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, dst);
+                else launch_gauss_pass<double>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, dst);
+                bytes += (double)n * ((first ? sizeof(TIN) : 8.0) + 8.0);
+            }
+            launches++;
+            if (!stored) {
+                cur = dst;
+                dst = (dst == bufA) ? bufB : bufA;
+            }
+        }
+        if (np == 0) {  // no filtering at all: normalisation only (a radius-0 pass)
             int r0;
             const double *dw = e.gauss_kernel(0.0, truncate, r0);  // radius 0: the single tap 1.0
             launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, 3, dw, 0, dst);
             cur = dst;
-            passes++;
+            launches++;
+            bytes += (double)n * (sizeof(TIN) + 8.0);
         }
-        if (out_dtype == FR3D_F64) launch_store_channel<double>(e.st, cur, n, C, c, (double *)out);
-        else launch_store_channel<float>(e.st, cur, n, C, c, (float *)out);
-        sp.add(8.0 * (double)n * 2.0 * passes, passes + 1, n);
+        if (!stored) {
+            if (out_dtype == FR3D_F64) launch_store_channel<double>(e.st, cur, n, C, c, (double *)out);
+            else launch_store_channel<float>(e.st, cur, n, C, c, (float *)out);
+            launches++;
+            bytes += (double)n * (8.0 + (out_dtype == FR3D_F64 ? 8.0 : 4.0));
+        }
+        // algorithmic bytes as for the resampler: per pass one read and one write of the volume in the
+        // pass's own element types
+        sp.add(bytes, launches, n);
     }
 }
 

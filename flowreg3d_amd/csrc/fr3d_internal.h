@@ -406,6 +406,11 @@ void launch_gauss_pass(hipStream_t st, const TIN *in, int cs, int co, double nmi
                        int Y, int X, int axis, const double *w, int radius, double *out);
 template <typename TOUT>
 void launch_store_channel(hipStream_t st, const double *in, long long n, int C, int c, TOUT *out);
+// radius-4 pass (sigma 1): normalise once per loaded element (NORM), register window / LDS segment, output element e at
+// out[e * ocs + oco] in TOUT (the last pass of a channel writes the caller's channels-last array); false = not covered
+template <typename TIN, typename TOUT, bool NORM>
+bool launch_gauss_pass4(hipStream_t st, const TIN *in, int cs, int co, double nmin, double nden, int T, int Z, int Y, int X,
+                        int axis, const double *w, int radius, TOUT *out, int ocs, int oco);
 
 // f-2 statistics (k_misc.hip): partial = nblocks x 6 doubles (sum|w|, max|w|, sum div, sum u, sum v, sum w)
 void launch_flow_stats(hipStream_t st, const float *flow, int Z, int Y, int X, int nblocks, double *partial);
