@@ -45,6 +45,16 @@ class DeviceBuffer:
             _lib.check(self._lib.fr3d_d2h(out.ctypes.data, self.at(t0), out.nbytes))
         return out
 
+    def download_into(self, out: np.ndarray, t0: int = 0):
+        """elements [t0, t0 + len(out)) straight into a C-contiguous host array (or slice) of this buffer's dtype"""
+        if out.dtype != self.dtype or not out.flags["C_CONTIGUOUS"] or out.shape[1:] != self.shape[1:]:
+            raise ValueError("download_into needs a C-contiguous array of the buffer's dtype and trailing shape")
+        if t0 + out.shape[0] > self.shape[0]:
+            raise ValueError("download past the end of the device buffer")
+        if out.nbytes:
+            _lib.check(self._lib.fr3d_d2h(out.ctypes.data, self.at(t0), out.nbytes))
+        return out
+
     def free(self):
         if self.ptr:
             self._lib.fr3d_dev_free(self.ptr)

@@ -189,9 +189,16 @@ class BatchMotionCorrectorHip:
         the optional reference update all run on device-resident data)."""
         if sink == "device":
             return self._run_device(np.asarray(video), reference)
-        if sink != "host":
-            raise ValueError("sink must be 'host' or 'device'")
+        if sink not in ("host", "host_arrays"):
+            raise ValueError("sink must be 'host', 'host_arrays' or 'device'")
         video = np.asarray(video)
+        from .executor import _RAW_CODES
+        if sink == "host" and video.dtype in _RAW_CODES and video.ndim == 5 and type(self.executor) is HipExecutor3D:
+            # the same driver on device-resident batches: the raw batch goes up once, preprocessing / flow / warp /
+            # w_init means / statistics run in HBM, and only `registered` and `w` of each batch come back (the float64
+            # `batch_proc` of the array path below never crosses PCIe: 4x the raw volume each way)
+            # ("host_arrays": the array-at-a-time path below, what a custom executor or another dtype takes)
+            return self._run_device(video, reference, host=True)
         T = video.shape[0]
         self._total, self._done = T, 0
         self._setup_reference(reference)
@@ -228,8 +235,10 @@ class BatchMotionCorrectorHip:
             self.executor.cleanup()
         return registered, flows
 
-    def _run_device(self, video: np.ndarray, reference: np.ndarray):
-        """The same driver with every per-voxel array resident in HBM (same arithmetic, same call order)."""
+    def _run_device(self, video: np.ndarray, reference: np.ndarray, host: bool = False):
+        """The same driver with every per-voxel array resident in HBM (same arithmetic, same call order).
+        ``host``: the outputs of each batch are fetched into NumPy arrays (-> registered, flows) and the device holds one
+        batch of them; otherwise the whole series' outputs stay in a DeviceSink."""
         from .device import DeviceBuffer, DeviceSink
         from .executor import _RAW_CODES
         from .preprocess import _DTYPES, _norm_constants, _sigma_table
@@ -254,7 +263,9 @@ class BatchMotionCorrectorHip:
         mins = np.ascontiguousarray(mins, np.float64)
         dens = np.ascontiguousarray(dens, np.float64)
         tab = _sigma_table(np.asarray(_opt(self.options, "sigma", None)), nc)
-        sink = DeviceSink(T, Z, Y, X, nc, video.dtype)
+        sink = DeviceSink(min(bs, T) if host else T, Z, Y, X, nc, video.dtype)
+        registered = np.empty_like(video) if host else None
+        flows = np.empty((T, Z, Y, X, 3), np.float32) if host else None
         bufs = []
 
         def dev(shape, dtype, init=None):
@@ -295,7 +306,8 @@ class BatchMotionCorrectorHip:
                 if upd_ref:
                     _lib.check(lib.fr3d_preprocess_dev(raw.ptr, _DTYPES[video.dtype], n, Z, Y, X, nc, mins.ctypes.data_as(dp),
                                                        dens.ctypes.data_as(dp), tab.ctypes.data_as(dp), 4.0, proc64.ptr, _lib.F64))
-                fl_ptr, reg_ptr = sink.flows_dev.at(t0), sink.registered_dev.at(t0)
+                o0 = 0 if host else t0  # where this batch's outputs sit in the sink
+                fl_ptr, reg_ptr = sink.flows_dev.at(o0), sink.registered_dev.at(o0)
                 if bi == 0:  # w_init = mean flow of the first min(22, T) volumes solved from zero (:342-393)
                     n_init = min(22, n)
                     process(n_init, zero.ptr, fl_ptr, reg_ptr, False)
@@ -303,7 +315,7 @@ class BatchMotionCorrectorHip:
                 process(n, w_init.ptr if use_init else zero.ptr, fl_ptr, reg_ptr, True)
                 if use_init:  # mean of the last <= 20 flows of the batch (:481-485)
                     k = min(n, 20)
-                    _lib.check(lib.fr3d_mean_stack_dev(sink.flows_dev.at(t0 + n - k), k, nv * 3, w_init.ptr))
+                    _lib.check(lib.fr3d_mean_stack_dev(sink.flows_dev.at(o0 + n - k), k, nv * 3, w_init.ptr))
                 _lib.check(lib.fr3d_flow_stats_dev(fl_ptr, n, Z, Y, X, stats.ctypes.data_as(dp)))
                 self.stats.mean_disp.extend(stats[:n, 0].tolist())
                 self.stats.max_disp.extend(stats[:n, 1].tolist())
@@ -315,7 +327,10 @@ class BatchMotionCorrectorHip:
                     self.reference_proc = new_ref64.download()
                     ref_proc64.upload(self.reference_proc)
                     ref_proc.upload(self.reference_proc)
-                sink.filled = t0 + n
+                if host:
+                    sink.registered_dev.download_into(registered[t0:t0 + n])
+                    sink.flows_dev.download_into(flows[t0:t0 + n])
+                sink.filled = n if host else t0 + n
             self.w_init = w_init.download()
         except Exception:
             sink.free()
@@ -323,6 +338,9 @@ class BatchMotionCorrectorHip:
         finally:
             for b in bufs:
                 b.free()
+        if host:
+            sink.free()
+            return registered, flows
         return sink
 
 

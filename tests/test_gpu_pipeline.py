@@ -130,7 +130,12 @@ def test_device_sink_gives_the_host_path_results(hip, dtype, update_ref):
               update_reference=update_ref)
     calls = []
     host = BatchMotionCorrectorHip(Options(**kw))
-    reg_h, w_h = host.run(video, ref)
+    reg_h, w_h = host.run(video, ref, sink="host_arrays")  # the array-at-a-time driver (custom executors, other dtypes)
+    # the default host sink streams the batches through the device driver and fetches each batch's outputs
+    stream = BatchMotionCorrectorHip(Options(**kw))
+    reg_s, w_s = stream.run(video, ref)
+    assert np.array_equal(w_s, w_h) and np.array_equal(reg_s, reg_h) and reg_s.dtype == dtype
+    assert np.array_equal(stream.w_init, host.w_init)
     dev = BatchMotionCorrectorHip(Options(**kw))
     dev.register_progress_callback(lambda d, t: calls.append((d, t)))
     sink = dev.run(video, ref, sink="device")
