@@ -66,6 +66,7 @@ SIGNATURES = {
     "fr3d_set_batch": (C.c_int, [C.c_int]),
     "fr3d_set_lanes": (C.c_int, [C.c_int]),
     "fr3d_last_solver_mode": (C.c_int, []),
+    "fr3d_last_solver_fallback": (C.c_int, []),
     "fr3d_get_displacement": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "fr3d_get_displacement_dev": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "fr3d_get_displacement_verify": (C.c_int, [C.POINTER(Params), _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -229,6 +230,16 @@ def make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth,
     p.solver_fp64 = -1 if solver_fp64 is None else (int(solver_fp64) if solver_fp64 in (0, 1, 2, 3, True, False) else 1)
     p.solver_sweep = int(solver_sweep)  # 0 = the engine's choice, 1 = plane launches, 2 = window kernel (bit-identical)
     return p
+
+
+def warn_if_degraded():
+    """After a flow solve: FR3D_SOLVER_AUTO fell back from packed to fp32 solver storage for lack of device memory."""
+    if load().fr3d_last_solver_fallback():
+        import warnings
+        warnings.warn("flowreg3d_amd: not enough device memory for packed 42-bit solver storage at this volume size; the "
+                      "flow was solved with fp32 storage, which is outside the 1e-4 end-point-error bound against the CPU path "
+                      "at 512^3 and beyond (pass solver_fp64=3 to fail instead, or free device memory)", RuntimeWarning,
+                      stacklevel=3)
 
 
 def prof_get() -> dict:

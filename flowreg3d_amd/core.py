@@ -128,6 +128,7 @@ def get_displacement(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=2
     lib = _lib.init()
     _lib.check(lib.fr3d_get_displacement(C.byref(params), _lib.ptr(f32), _lib.ptr(m32), p, m, n, nc,
                                          _lib.ptr(u32), _lib.ptr(w32), _lib.ptr(flow)))
+    _lib.warn_if_degraded()
     return flow.astype(np.float64)
 
 

@@ -225,6 +225,19 @@ struct Engine {
     std::map<std::tuple<int, int, long long>, DevTable> tables;  // (in,out,sigma bits)
     std::map<std::tuple<int, int, int, int, int>, SorSched> scheds;  // (Z,Y,X,iterations,lag) of a level (a_smooth != 1)
     std::map<std::tuple<int, int, int, int, int, int>, SorChainSched> chain_scheds;  // (Z,Y,X,iterations,rows,chain): a_smooth == 1
+    int slab_slots = 0;  // volumes per lock-step batch the solver slabs were last sized for
+    // the per-volume solver slabs and level flows (everything get_displacement_core_t sizes by the batch)
+    void release_slabs()
+    {
+        for (auto &kv : bufs) {
+            const std::string &k = kv.first;
+            if (k.compare(0, 4, "M_sk") == 0 || k.compare(0, 4, "A_sk") == 0 || k.compare(0, 4, "L_sk") == 0 ||
+                k.compare(0, 4, "d_sk") == 0 || k.compare(0, 4, "E_sk") == 0 || k.compare(0, 3, "sm_") == 0 ||
+                k.compare(0, 3, "uvw") == 0)
+                kv.second.release();
+        }
+        slab_slots = 0;
+    }
     std::map<std::tuple<int, int, int, int>, WinSched> win_scheds;  // (Z,Y,iterations,update_lag): window sweep
     const WinSched &win_sched(const Skew &sk, int iterations, int update_lag)
     {
@@ -531,6 +544,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         const Skew sk = e.compact_skew(lz, ly, lx);
         const size_t ns = (size_t)sk.total;
         const size_t nres = (size_t)std::max(nb, reserve_nb);  // slabs reserved (>= nb)
+        e.slab_slots = std::max(e.slab_slots, (int)nres);
         // sizes and strides in storage elements (sto_elems: values for float / double, 4 dwords per 3 values for pk42)
         const size_t e3 = (size_t)sto_elems<S>((long long)ns * 3), e9 = 3 * e3, e12 = 4 * e3;
         S *Mbuf = (S *)e.bufs["M_sk" + sn].ensure(e9 * nres * sizeof(S));
@@ -1012,13 +1026,14 @@ static double solver_bytes_per_volume(const std::vector<Level> &lv, int C, doubl
     // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
     return total * bytes * (12.0 * C + 9.0 + 6.0 + (fast_path ? 0.0 : 13.0)) + nfin * 4.0 * 9.0;
 }
-static double solver_budget(const std::vector<Level> &lv, int C)
+// `lanes`: engine lanes the call will run on -- each holds its own per-level scratch
+static double solver_budget(const std::vector<Level> &lv, int C, int lanes = 1)
 {
     const Level &F = lv.back();
     const double nfin = (double)F.z * F.y * F.x;
-    // volume-independent scratch of the finest level: moving level and its warp (2C), fp64 spline coefficients and
-    // the y-pass scratch (~4.2), increments and their median (6), reference and weight pyramids (~4C)
-    const double scratch = nfin * 4.0 * (2.0 * C + 4.2 + 6.0 + 4.0 * C);
+    // volume-independent scratch of the finest level, per lane: moving level and its warp (2C), fp64 spline coefficients
+    // and the y-pass scratch (~4.2), increments and their median (6); once: reference and weight pyramids (~4C)
+    const double scratch = nfin * 4.0 * (lanes * (2.0 * C + 4.2 + 6.0) + 4.0 * C);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return -1.0;
     // what the solver slabs may occupy: the memory that is free now plus what the engine already
@@ -1029,11 +1044,15 @@ static double solver_budget(const std::vector<Level> &lv, int C)
     for (const Engine *en : {&g_eng, &g_eng2})
         for (const auto &kv : en->bufs)
             if (kv.first.compare(0, 3, "stg") != 0) held += kv.second.cap;
-    const double avail = (double)free_b + (double)held - scratch - 2.0 * 1073741824.0;
+    double avail = (double)free_b + (double)held - scratch - 2.0 * 1073741824.0;
+    // FR3D_MEM_CAP_MIB: pretend the device is this small (tests of the batch / lane decisions under a tight budget)
+    static const char *cap_env = getenv("FR3D_MEM_CAP_MIB");
+    if (cap_env && atof(cap_env) > 0.0) avail = std::min(avail, atof(cap_env) * 1048576.0);
     return std::min(0.85 * (double)total_b, avail);
 }
 
 static std::atomic<int> g_last_mode{-1};  // fr3d_last_solver_mode(); both lanes store the same value
+static std::atomic<int> g_last_fallback{0};  // fr3d_last_solver_fallback()
 
 // The solver mode of a call: solver_mode(), except that an AUTOMATIC choice of packed storage falls back to fp32
 // storage when one volume's packed slabs do not fit the device and its fp32 slabs do (one 1024^3 volume: 164 GB of
@@ -1041,23 +1060,27 @@ static std::atomic<int> g_last_mode{-1};  // fr3d_last_solver_mode(); both lanes
 static int resolve_mode(const fr3d_params &p, int C, int Z, int Y, int X, const std::vector<Level> &lv)
 {
     int m = solver_mode(p, C, (long long)Z * Y * X);
+    int fell = 0;
     if (p.solver_fp64 < 0 && m == 3) {
         const double budget = solver_budget(lv, C);
         if (budget > 0 && solver_bytes_per_volume(lv, C, 16.0 / 3.0, true) > budget &&
-            solver_bytes_per_volume(lv, C, 4.0, true) <= budget)
+            solver_bytes_per_volume(lv, C, 4.0, true) <= budget) {
             m = 1;
+            fell = 1;
+        }
     }
     g_last_mode = m;
+    g_last_fallback = fell;
     return m;
 }
 
-static int pick_batch(int T, const std::vector<Level> &lv, int C)
+static int pick_batch(int T, const std::vector<Level> &lv, int C, int lanes = 1)
 {
     int want = batch_wanted();
     if (want > T) want = T;
     if (want < 1) want = 1;
     const double per_vol = solver_bytes_per_volume(lv, C, g_storage_bytes, g_fast_path);
-    const double budget = solver_budget(lv, C);
+    const double budget = solver_budget(lv, C, lanes);
     if (budget > 0)
         while (want > 1 && per_vol * want > budget) want--;
     return want;
@@ -1192,13 +1215,26 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     }
     g_fast_path = p->a_smooth == 1.0;
     int B = T > 0 ? pick_batch(T, lv, C) : 1;
-    // two lanes: each takes lock-step batches of half the size (same workspace in total), alternately
-    // (profiling brackets imply one lane: the HIP-event spans of two lanes overlap and are not kernel times)
-    const bool two = g_lanes == 2 && g_eng2.inited && !e.prof && T >= 2 && B >= 2;
-    if (two) B = cdiv(B, 2);
-    else
+    // two lanes: each takes lock-step batches of half the size, alternately (profiling brackets imply one lane: the
+    // HIP-event spans of two lanes overlap and are not kernel times).  The budget is that of the layout that runs:
+    // the volumes that fit beside TWO lanes' scratch, halved and rounded DOWN (an odd count must not become 2 x the
+    // larger half); no room for one volume per lane -> one lane.
+    bool two = g_lanes == 2 && g_eng2.inited && !e.prof && T >= 2 && B >= 2;
+    if (two) {
+        const int B2 = pick_batch(T, lv, C, 2) / 2;
+        if (B2 >= 1) B = B2;
+        else two = false;
+    }
+    if (!two)
         for (auto &kv : g_eng2.bufs) kv.second.release();  // one lane: the other lane's workspace is not reusable here
-    const int reserve = g_batch_hint > 0 ? std::max(1, pick_batch(g_batch_hint, lv, C) / (two ? 2 : 1)) : B;
+    const int reserve = g_batch_hint > 0 ? std::max(1, pick_batch(g_batch_hint, lv, C, two ? 2 : 1) / (two ? 2 : 1)) : B;
+    // Buffers never shrink by themselves: slabs that an earlier call sized for more volumes per lane than this one
+    // holds (a one-lane call before a two-lane call: every profiled pass) would sit beside the other lane's new slabs
+    // although the budget above counts them as reusable.  Give them back first.
+    for (Engine *en : {&g_eng, &g_eng2})
+        if (en->slab_slots > std::max(B, reserve)) {
+            en->release_slabs();
+        }
     // the solver mode is settled here, once: the lanes then never look at the memory budget (and at each other's
     // workspace tables) while they run
     fr3d_params pr = *p;
@@ -1256,15 +1292,38 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
         throw;
     }
     const int device = e.device;
+    // The progress callback runs on the CALLER's thread only (the reference's executors call it there, and the caller
+    // holds this library's lock: a callback that re-enters the library from lane 1's thread would wait for it forever).
+    // Lane 1 posts the volumes of its finished batches; the caller's thread delivers them whenever it reports its own
+    // and while it waits for lane 1 at the end.
     std::mutex progress_mu;
+    std::condition_variable progress_cv;
+    int posted = 0;          // volumes finished on lane 1, not yet delivered
+    bool lane1_done = false;
+    auto deliver_posted = [&]() {  // caller's thread
+        int n;
+        {
+            std::lock_guard<std::mutex> lk(progress_mu);
+            n = posted;
+            posted = 0;
+        }
+        if (progress)
+            for (int b = 0; b < n; b++) progress(1, user);
+    };
     auto feed = [&](Engine &lane, int parity, std::exception_ptr &err) {
         std::vector<std::pair<hipEvent_t, int>> pending;  // completion event and volume count of this lane's batches
         auto report = [&](size_t upto) {  // wait for this lane's batches [reported, upto) and report them
             for (; !pending.empty() && upto > 0; upto--) {
                 FR3D_HIP(hipEventSynchronize(pending.front().first));
                 if (progress) {
-                    std::lock_guard<std::mutex> lk(progress_mu);
-                    for (int b = 0; b < pending.front().second; b++) progress(1, user);
+                    if (parity == 0) {
+                        deliver_posted();
+                        for (int b = 0; b < pending.front().second; b++) progress(1, user);
+                    } else {
+                        std::lock_guard<std::mutex> lk(progress_mu);
+                        posted += pending.front().second;
+                        progress_cv.notify_one();
+                    }
                 }
                 (void)hipEventDestroy(pending.front().first);
                 pending.erase(pending.begin());
@@ -1291,8 +1350,21 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
             for (auto &pe : pending) (void)hipEventDestroy(pe.first);
         }
     };
-    std::thread other(feed, std::ref(g_eng2), 1, std::ref(err1));
+    std::thread other([&]() {
+        feed(g_eng2, 1, err1);
+        std::lock_guard<std::mutex> lk(progress_mu);
+        lane1_done = true;
+        progress_cv.notify_one();
+    });
     feed(e, 0, err0);
+    for (;;) {  // lane 0 is through: hand on lane 1's volumes as they finish
+        std::unique_lock<std::mutex> lk(progress_mu);
+        progress_cv.wait(lk, [&]() { return posted > 0 || lane1_done; });
+        const bool done = lane1_done;
+        lk.unlock();
+        deliver_posted();
+        if (done) break;
+    }
     other.join();
     (void)hipEventDestroy(ev_start);
     if (err0) std::rethrow_exception(err0);
@@ -1552,6 +1624,7 @@ const char *fr3d_device_info(void)
 }
 
 int fr3d_last_solver_mode(void) { return g_last_mode; }
+int fr3d_last_solver_fallback(void) { return g_last_fallback; }
 
 int fr3d_set_batch(int nvol)
 {

@@ -48,10 +48,15 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
     // 8 xg tiles an XCD takes xg CONSECUTIVE tiles of the list (a few neighbouring row blocks), while all XCDs stay in
     // the same neighbourhood of memory; the tail of the list keeps its order; xg = 0: blockIdx order.
     // (One contiguous eighth of the list per XCD loses 5-7 % at 256^3: profiles/r03/sor_xcd_swizzle_ab.txt.)
+    // (the XCD follows the LINEAR workgroup id, blockIdx.y * gridDim.x + blockIdx.x: the volumes of a lock-step batch
+    // after the first start on a shifted XCD whenever the tile count is not a multiple of 8)
     int b = blockIdx.x;
     if (xg > 0) {
         const int run = 8 * xg, full = (int)(gridDim.x / run) * run;
-        if (b < full) b = (b / run) * run + (b & 7) * xg + ((b >> 3) % xg);
+        if (b < full) {
+            const int off = (int)((blockIdx.y * gridDim.x) & 7u), p = b % run;
+            b = (b / run) * run + ((p + off) & 7) * xg + (p >> 3);
+        }
     }
     // find the group: the table gives the entry of the first tile of this tile group, a short
     // forward scan does the rest (a bisection costs ~7 dependent scalar loads before the first

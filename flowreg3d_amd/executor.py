@@ -181,6 +181,7 @@ class HipExecutor3D:
         _lib.check(lib.fr3d_process_batch_raw(C.byref(params), _lib.ptr(bp), _lib.ptr(br), code, _lib.ptr(rp),
                                               _lib.ptr(rr), ref_code, _lib.ptr(wi), _lib.ptr(w32), T, Z, Y, X, nc, order,
                                               _lib.ptr(flows), _lib.ptr(reg_dev), cb, None))
+        _lib.warn_if_degraded()
         if cb_error:
             raise cb_error[0]
         if not direct:
@@ -233,6 +234,7 @@ class HipExecutor3D:
                                                       ref_ptrs["reference_raw"], _lib.F32, ref_ptrs.get("w_init"),
                                                       ref_ptrs.get("weight"), T, Z, Y, X, nc, order, d_flows.ptr, d_reg.ptr,
                                                       cb, None))
+            _lib.warn_if_degraded()
             if cb_error:
                 raise cb_error[0]
             flows = d_flows.download()

@@ -77,6 +77,10 @@ typedef struct fr3d_params {
  * automatic choice of packed storage falls back to fp32 storage when one volume's packed solver slabs do not fit the
  * device's free memory and the fp32 slabs do.  -1 before the first solve. */
 int fr3d_last_solver_mode(void);
+/* 1 if that solve was an automatic choice that DEGRADED from packed 42-bit to fp32 storage for lack of device memory
+ * (volumes of the 1024^3 class): the flow is then outside the 1e-4 parity bound the automatic modes are chosen for
+ * (fp32 storage measures 1.5e-4 at 512^3 already; profiles/parity_fullsize.json).  The Python mirror warns. */
+int fr3d_last_solver_fallback(void);
 
 /* ---- lifetime ------------------------------------------------------------------------- */
 int fr3d_init(int device);              /* hipSetDevice + stream + workspace; idempotent */

@@ -193,3 +193,80 @@ def test_two_engine_lanes_give_the_one_lane_results_bit_for_bit(hip, C, a_smooth
         finally:
             lib.fr3d_set_lanes(2)
             lib.fr3d_set_batch(0)
+
+
+def test_progress_callback_runs_on_the_callers_thread_and_may_reenter_the_library(hip):
+    """Two engine lanes: lane 1 is fed by a thread of the library, but the progress callback is delivered on the CALLER's
+    thread (where the reference's executors call it, and where a GUI progress bar lives) -- and it may call back into the
+    library (the caller's thread holds the library's recursive lock; from another thread that would deadlock)."""
+    import threading
+    from flowreg3d_amd import _lib
+    from flowreg3d_amd.executor import HipExecutor3D
+    fixed, batch = _series(T=6)
+    w0 = np.zeros(batch.shape[1:4] + (3,), np.float32)
+    fp = dict(alpha=(0.25,) * 3, update_lag=5, iterations=5, min_level=0, levels=2, eta=0.8, a_smooth=1.0, a_data=0.45)
+    lib = _lib.load()
+    prev = lib.fr3d_set_lanes(2)
+    seen = []
+
+    def cb(k):
+        seen.append((int(k), threading.get_ident()))
+        assert lib.fr3d_sync() == 0          # re-enters the library
+        lib.fr3d_last_error()
+
+    try:
+        lib.fr3d_set_batch(2)                # 6 volumes as chunks of 1 on two lanes
+        HipExecutor3D().process_batch(batch, batch, fixed, fixed, w0, None, None, progress_callback=cb, flow_params=fp)
+    finally:
+        lib.fr3d_set_batch(0)
+        lib.fr3d_set_lanes(prev)
+    assert sum(k for k, _ in seen) == 6
+    assert {t for _, t in seen} == {threading.get_ident()}
+
+
+def test_tight_memory_budget_odd_batch_one_lane_then_two_lanes(hip):
+    """the two-lane split must budget for the layout that runs.  A device that "has room" for three volumes
+    (FR3D_MEM_CAP_MIB) runs them as 1 + 1 + 1 on two lanes, not 2 + 2; a one-lane call (profiling brackets on) before it
+    leaves slabs sized for three volumes behind, which are given back; results equal the uncapped run's."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from flowreg3d_amd import _lib
+from flowreg3d_amd.executor import HipExecutor3D
+from flowreg3d_amd.synthetic import make_pair
+shape = (40, 48, 44)
+fixed, _, _ = make_pair(shape, seed=3)
+batch = np.stack([make_pair(shape, seed=3, scale=s)[1] for s in (0.2, 0.4, 0.6, 0.8, 1.0)])[..., None]
+ref = fixed[..., None]
+w0 = np.zeros(shape + (3,), np.float32)
+fp = dict(alpha=(0.25,) * 3, update_lag=5, iterations=10, min_level=0, levels=2, eta=0.8, a_smooth=1.0, a_data=0.45, solver_fp64=2)
+lib = _lib.init(0)
+ex = HipExecutor3D()
+lib.fr3d_prof_enable(1)                       # one lane: slabs for the whole budgeted batch
+_, f1 = ex.process_batch(batch, batch, ref, ref, w0, None, None, flow_params=fp)
+lib.fr3d_prof_enable(0)                       # two lanes
+_, f2 = ex.process_batch(batch, batch, ref, ref, w0, None, None, flow_params=fp)
+np.save(sys.argv[1], np.stack([f1, f2]))
+'''
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag in ("free", "tight"):
+            env = dict(os.environ)
+            if tag == "tight":
+                env["FR3D_MEM_CAP_MIB"] = str(outs["cap"])  # room for three volumes' solver slabs
+            path = os.path.join(td, tag + ".npy")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[tag] = np.load(path)
+            if tag == "free":
+                nfin = 40 * 48 * 44
+                per_vol = 1.3 * nfin * 8.0 * (12 + 9 + 6) + nfin * 36.0   # solver_bytes_per_volume's formula, roughly
+                outs["cap"] = int(3.4 * per_vol / 1048576.0) + 1
+    assert np.array_equal(outs["free"][0], outs["free"][1])          # one lane == two lanes
+    assert np.array_equal(outs["tight"][0], outs["free"][0])
+    assert np.array_equal(outs["tight"][1], outs["free"][0])
