@@ -184,15 +184,33 @@ def process_series_sharded(batch: Optional[np.ndarray], batch_proc: Optional[np.
         executor.setup()
 
     def windows():
-        """this rank's volumes as (raw, proc) stacks, one window at a time"""
+        """this rank's volumes as (raw, proc) stacks, one window at a time.  Window k+1 is loaded on a host thread
+        while the engine computes window k (the reference's executors overlap reader and workers the same way,
+        parallelization/multiprocessing_3d.py:286-318): with window < shard the GPU no longer idles during load_volume.
+        Host memory holds two windows of inputs."""
         if load_volume is None:
             if mine:
                 yield batch[mine], batch_proc[mine]
             return
         step = len(mine) if not window else max(1, int(window))
-        for i in range(0, len(mine), max(step, 1)):
+        starts = list(range(0, len(mine), max(step, 1)))
+
+        def load(i):
             pairs = [load_volume(t) for t in mine[i:i + step]]
-            yield np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+            return np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+
+        if len(starts) <= 1:
+            for i in starts:
+                yield load(i)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="fr3d-load") as pool:
+            nxt = pool.submit(load, starts[0])
+            for n, i in enumerate(starts):
+                cur = nxt.result()
+                if n + 1 < len(starts):
+                    nxt = pool.submit(load, starts[n + 1])  # runs while the caller processes `cur`
+                yield cur
 
     def collect(run):
         regs, flws = [], []

@@ -89,3 +89,74 @@ def test_broadcast_is_identity_without_process_group():
     from flowreg3d_amd.distributed import broadcast_reference
     p = {"a": np.ones(3, np.float32), "b": None}
     assert broadcast_reference(p) is p
+
+
+def _prefetch_worker(rank, world, port, q):
+    """windows of one volume: the loader must be called for window k+1 BEFORE process_batch of window k returns"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import threading
+    import time
+    import torch.distributed as dist
+    from flowreg3d_amd.distributed import process_series_sharded, shard_indices
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fixed, batch, w0, fp = _series()
+        events = []
+        lock = threading.Lock()
+
+        def load_volume(t):
+            with lock:
+                events.append(("load", t, threading.get_ident()))
+            return batch[t], batch[t]
+
+        class Slow(OracleExecutor):
+            def process_batch(self, b, bp, *a, **k):
+                with lock:
+                    events.append(("begin", None, threading.get_ident()))
+                out = super().process_batch(b, bp, *a, **k)
+                time.sleep(0.3)  # the next window's load has ample time to start
+                with lock:
+                    events.append(("end", None, threading.get_ident()))
+                return out
+
+        args = (None, None, fixed, fixed, w0, fp) if rank == 0 else (None, None, None, None, None, None)
+        mine, reg, flows = process_series_sharded(*args, executor=Slow(), load_volume=load_volume, n_volumes=5, window=1)
+        assert mine == shard_indices(5, rank, world)
+        q.put((rank, mine, events, reg, flows))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_loader_prefetches_the_next_window_world2():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_prefetch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fixed, batch, w0, fp = _series()
+    seq_reg, seq_flows = OracleExecutor().process_batch(batch, batch, fixed, fixed, w0, None, None, flow_params=fp)
+    for rank, mine, events, reg, flows in got:
+        kinds = [e[0] for e in events]
+        # every volume of the shard was loaded exactly once, in order
+        assert [e[1] for e in events if e[0] == "load"] == mine
+        # window k+1's load is called BEFORE process_batch of window k returns, on another thread
+        main_thread = next(e[2] for e in events if e[0] == "begin")
+        for k in range(len(mine) - 1):
+            e = [i for i, x in enumerate(kinds) if x == "end"][k]
+            nxt = next(i for i, x in enumerate(events) if x[0] == "load" and x[1] == mine[k + 1])
+            assert nxt < e, (rank, k, kinds)
+            assert events[nxt][2] != main_thread
+        # and the results are those of the sequential run
+        assert np.array_equal(flows, seq_flows[mine]) and np.array_equal(reg, seq_reg[mine])
