@@ -167,6 +167,12 @@ def fullsize_case(name, warp=None):
         gt = flow_gt((n, n, n), scale=1.35 if name.endswith("_s135") else 1.0)
         moving = np.asarray(warp(fixed, -gt[..., 0], -gt[..., 1], -gt[..., 2], fixed), dtype=np.float32).reshape(fixed.shape)
         return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=4 if n == 256 else 5)
+    if name in ("thr_160x176x176", "thr_200"):
+        # single-channel volumes just above FR3D_SOLVER_AUTO's switch from fp32 to packed solver storage (2^22 voxels):
+        # 4.96 M and 8 M voxels, a non-cubic and a cubic one (the switch point was pinned at 128^3 and 256^3 only)
+        shape = (160, 176, 176) if name == "thr_160x176x176" else (200, 200, 200)
+        fixed, moving, gt = fast_pair(shape)
+        return fixed, moving, gt, dict(SOLVER_DEFAULTS, levels=4)
     if name == "cfg5_levels8":
         # the survey's own config-5 schedule (levels=8, min_level=0 -> 9 solves); the pyramid does
         # not capture the 23-voxel corner motion (CPU and GPU both end 3.45 voxels from the ground truth), which is

@@ -8,7 +8,7 @@ import numpy as np
 
 from conftest import golden
 
-CASES = ["drv_t3_serial", "drv_t7_b5", "drv_t7_b3", "drv_noinit", "drv_c2_u16"]
+CASES = ["drv_t3_serial", "drv_t7_b5", "drv_t7_b3", "drv_noinit", "drv_c2_u16", "drv_consistency"]
 OUT_DTYPES = {"single": np.float32, "double": np.float64, "uint8": np.uint8, "uint16": np.uint16, "int16": np.int16,
               "int32": np.int32}
 
@@ -20,7 +20,8 @@ def load_case(name):
     meta = json.loads(bytes(g["meta"]).decode())
     o = dict(meta["options"])
     o.pop("verbose", None)
-    opt = Options(alpha=tuple(o["alpha"]), weight=o["weight"], levels=o["levels"], min_level=o["min_level"], eta=o["eta"],
+    opt = Options(alpha=tuple(o["alpha"]), weight=o["weight"], levels=o["levels"], min_level=o["min_level"],
+                  quality_setting=o.get("quality_setting", "quality"), eta=o["eta"],
                   update_lag=o["update_lag"], iterations=o["iterations"], a_smooth=o["a_smooth"], a_data=o["a_data"],
                   sigma=o["sigma"], buffer_size=o["buffer_size"], output_typename=o.get("output_typename", "double"),
                   channel_normalization=o.get("channel_normalization", "together"),
@@ -97,6 +98,37 @@ def oracle_driver(oracle, video, reference, opt):
     return reg, w, stats, w_init
 
 
+def record_registered(label, d, reg_ref, epe):
+    """append the measured `registered` difference of a GPU run against the reference's output to
+    gpurun_out/parity_registered.json (the committed copy, profiles/parity_registered.json, is where the default-mode
+    bound below comes from)"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "parity_registered.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except (OSError, ValueError):
+        rec = {}
+    ptp = float(np.ptp(reg_ref.astype(np.float64)))
+    rec[label] = {"registered_max_abs_diff": float(d.max()), "registered_mean_abs_diff": float(d.mean()),
+                  "reference_range": ptp, "max_diff_over_range": float(d.max()) / ptp if ptp > 0 else None,
+                  "flow_epe_mean": float(epe.mean()), "flow_epe_max": float(epe.max()), "dtype": str(reg_ref.dtype)}
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(rec, fh, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+# Default solver mode, float volumes: |registered - reference's registered| <= DEFAULT_REG_REL x the intensity range.
+# Measured (profiles/parity_registered.json, every driver / executor fixture in the default mode): see DESIGN.md section 2;
+# the flow differs from the CPU path's by <= 1e-4 voxels in the mean and a few 1e-3 at single voxels, and a warp turns a
+# flow difference e into an intensity difference of about |grad I| e <= (range / a few voxels) e.
+DEFAULT_REG_REL = 2e-3
+
+
 def check_against_reference(g, reg, w, stats, w_init, flow_tol, label, parity_grade=True):
     """registered / w / statistics / final w_init of a driver run against the reference's own outputs."""
     reg_ref, w_ref = g["registered"], g["w"]
@@ -106,6 +138,7 @@ def check_against_reference(g, reg, w, stats, w_init, flow_tol, label, parity_gr
     d = np.abs(reg.astype(np.float64) - reg_ref.astype(np.float64))
     info = f"{label}: flow EPE vs reference mean {epe.mean():.2e} max {epe.max():.2e}; registered |diff| max {d.max():.3e}"
     print(info)
+    record_registered(label, d, reg_ref, epe)
     assert epe.mean() < flow_tol, info
     if np.issubdtype(reg_ref.dtype, np.integer):
         # SciPy rounds into the raw dtype: a 1e-6-voxel flow difference can flip a value at x.5 by one count
@@ -113,7 +146,7 @@ def check_against_reference(g, reg, w, stats, w_init, flow_tol, label, parity_gr
     elif parity_grade:
         np.testing.assert_allclose(reg, reg_ref, rtol=1e-5, atol=1e-6, err_msg=info)
     else:
-        assert d.max() < 2e-5 * float(np.ptp(reg_ref)) + 1e-6 * float(np.abs(reg_ref).max()) + 0.05, info
+        assert d.max() <= DEFAULT_REG_REL * float(np.ptp(reg_ref)), info
     st = stats if isinstance(stats, dict) else {k: getattr(stats, k) for k in ("mean_disp", "max_disp", "mean_div", "mean_translation")}
     for k in ("mean_disp", "max_disp", "mean_translation"):
         assert np.allclose(st[k], g[k], rtol=1e-4, atol=1e-5), (label, k, st[k], g[k].tolist())

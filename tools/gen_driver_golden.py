@@ -23,6 +23,10 @@ Cases (branches of the driver they pin):
   drv_t7_b3       T=7, buffer_size=3: three batches, mean of each batch's flows carried forward
   drv_noinit      update_initialization_w=False (:470-473)
   drv_c2_u16      two channels with 1-D weights, uint16 series, output_typename="uint16" (compensate_arr_3D.py:112-125)
+  drv_consistency the inputs of the reference's OWN cross-executor test (tests/motion_correction/test_parallelization.py:
+                  152-198: seed 42, (8,6,12,12,2) uniform noise, reference = mean of the first two volumes,
+                  OFOptions(quality_setting="fast", levels=2, iterations=5), everything else default); that test holds
+                  its executors to rtol 1e-5 / atol 1e-6 of each other on `registered`
 
 Usage:  python tools/gen_driver_golden.py [--only NAME]
 """
@@ -101,15 +105,32 @@ def main():
                            opts=dict(base, weight=[0.7, 0.3], sigma=[[1.0, 1.0, 1.0, 0.1], [0.8, 0.8, 0.8, 0.2]],
                                      buffer_size=2, output_typename="uint16", channel_normalization="separate")),
     }
+    cases["drv_consistency"] = dict(own_test=True, opts=dict(quality_setting="fast", levels=2, iterations=5))
     for name, cs in cases.items():
         if args.only and args.only != name:
             continue
-        video, ref = series(cs["T"], cs["shape"], cs["C"], seed=7 * len(name), dtype=cs["dtype"])
-        if cs["squeeze"]:
-            video_in, ref_in = video[..., 0], ref[..., 0]
+        if cs.get("own_test"):
+            np.random.seed(42)  # as the reference's test does
+            video_in = np.random.rand(8, 6, 12, 12, 2).astype(np.float32)
+            ref_in = np.mean(video_in[:2], axis=0)
         else:
-            video_in, ref_in = video, ref
+            video, ref = series(cs["T"], cs["shape"], cs["C"], seed=7 * len(name), dtype=cs["dtype"])
+            if cs["squeeze"]:
+                video_in, ref_in = video[..., 0], ref[..., 0]
+            else:
+                video_in, ref_in = video, ref
         opt = OFOptions(**cs["opts"])
+        if cs.get("own_test"):
+            # record what the defaults resolved to, so that the product's Options can be built from the fixture alone
+            cs = dict(cs, opts=dict(alpha=[float(a) for a in np.atleast_1d(opt.alpha)], weight=[float(x) for x in np.atleast_1d(opt.weight)],
+                                    levels=int(opt.levels), min_level=int(opt.min_level), quality_setting=str(getattr(opt.quality_setting, "value", opt.quality_setting)),
+                                    eta=float(opt.eta), update_lag=int(opt.update_lag), iterations=int(opt.iterations),
+                                    a_smooth=float(opt.a_smooth), a_data=float(opt.a_data), sigma=np.asarray(opt.sigma).tolist(),
+                                    buffer_size=int(opt.buffer_size),
+                                    output_typename=getattr(opt, "output_typename", "double"),
+                                    channel_normalization=str(getattr(opt.channel_normalization, "value", opt.channel_normalization)),
+                                    interpolation_method=str(getattr(opt.interpolation_method, "value", opt.interpolation_method)),
+                                    update_initialization_w=bool(opt.update_initialization_w)))
         made.clear()
         seen = []
         t0 = time.time()

@@ -44,7 +44,8 @@ def sample(flow, stride, block):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("case", choices=("cfg2", "cfg2_asmooth05", "cfg3", "cfg5", "cfg2_recipe", "cfg3_recipe", "cfg2_recipe_s135", "cfg5_levels8"))
+    ap.add_argument("case", choices=("cfg2", "cfg2_asmooth05", "cfg3", "cfg5", "cfg2_recipe", "cfg3_recipe", "cfg2_recipe_s135", "cfg5_levels8",
+                                     "thr_160x176x176", "thr_200"))
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--stride", type=int, default=8)
     ap.add_argument("--block", type=int, default=32)
