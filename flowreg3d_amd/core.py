@@ -204,7 +204,8 @@ def imresize_fused_gauss_cubic3D(img, size, sigma_coeff=0.6, per_axis=False):
 
 def get_displacement_verify(fixed, moving, alpha=(2, 2, 2), update_lag=10, iterations=20, min_level=0,
                             levels=50, eta=0.8, a_smooth=1.0, a_data=0.45, uvw=None, weight=None):
-    """Verification mode of ``get_displacement`` (fr3d_get_displacement_verify, a_smooth == 1): the reference's own
+    """Verification mode of ``get_displacement`` (fr3d_get_displacement_verify; both solver branches, a_smooth == 1 and the
+    psi_smooth branch of level_solver_3d.py:262-311,400-471): the reference's own
     arithmetic (core/level_solver_3d.py:356-377,472-540: fp64, expanded quadratic form, per-channel order, true
     divisions) on the engine's data path, the level flow kept in float64 like the reference's.  Bit-identical to the
     CPU restatement of the reference built with the same portable pow (its ``ppow`` build); ~5x slower than the fp64-storage mode.
@@ -216,8 +217,6 @@ def get_displacement_verify(fixed, moving, alpha=(2, 2, 2), update_lag=10, itera
         moving = moving[..., None]
     if fixed.ndim != 4 or moving.shape != fixed.shape:
         raise ValueError("fixed and moving must have the same (Z,Y,X[,C]) shape")
-    if float(a_smooth) != 1.0:
-        raise NotImplementedError("the verification mode covers the a_smooth == 1 solver")
     p, m, n, nc = fixed.shape
     wt = None if is_default_weight(weight, nc) else expand_weight(weight, p, m, n, nc)
     params = _lib.make_params(alpha, update_lag, iterations, min_level, levels, eta, a_smooth, a_data, nc, 2)

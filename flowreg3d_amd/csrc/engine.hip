@@ -792,7 +792,6 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
                                     const RefPyramid &rp, const float *moving, int Z, int Y, int X, int C,
                                     const float *uvw_init, double *flow_out)
 {
-    FR3D_CHECK(p.a_smooth == 1.0, "verification mode covers the a_smooth == 1 solver");
     const size_t nfull = (size_t)Z * Y * X;
     double *ud[3] = {nullptr, nullptr, nullptr}, *ud_prev[3] = {nullptr, nullptr, nullptr};
     int pz = 0, py = 0, px = 0, flip = 0;
@@ -888,7 +887,25 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
         dump("warpedf", 0, warped, nl * C * sizeof(float));
         dump("uinitf", 0, uf, nl * 3 * sizeof(float));
 #endif
-        launch_sor_verify(e.st, a, e.chain_sched(sk, p.iterations));
+        if (p.a_smooth == 1.0) {
+            launch_sor_verify(e.st, a, e.chain_sched(sk, p.iterations));
+        } else {
+            // a_smooth != 1: psi_smooth of iteration t needs the whole field of t-1, so the iterations run one at a time
+            // (speed is not the point of this mode): psi_smooth on the padded grid, then the S hyperplane steps of ONE
+            // lexicographic sweep.  Dm2 = the increments two iterations back: the ghost ring the reference's padded
+            // arrays hold while psi_smooth is evaluated (set_boundary_3d ran before the previous sweep).
+            double *Dm2 = e.f64("vf_Dm2", ns * 3);
+            double *Ps = e.f64("vf_Ps", (size_t)(lz + 2) * (ly + 2) * (lx + 2));
+            FR3D_HIP(hipMemsetAsync(Dm2, 0, ns * 3 * sizeof(double), e.st));
+            a.Ps = Ps;
+            const SorChainSched &one = e.chain_sched(sk, 1);
+            for (int it = 0; it < p.iterations; it++) {
+                launch_psi_smooth_verify(e.st, sk, Urec, Drec, Dm2, p.a_smooth, hx, hy, hz, Ps);
+                FR3D_HIP(hipMemcpyAsync(Dm2, Drec, ns * 3 * sizeof(double), hipMemcpyDeviceToDevice, e.st));
+                a.t_base = it;
+                launch_sor_verify(e.st, a, one);
+            }
+        }
         // :517-529 in fp64: increments back to the natural order, 5^3 median, u = u + du
         double *dn = e.f64("vf_dnat", nl * 3);
         launch_unskew_unpack<double, double>(e.st, Drec, dn, (long long)nl, 3, sk);

@@ -210,9 +210,18 @@ struct VerifyArgs {
     double ax, ay, az;                   // alpha / h^2
     double a_data[FR3D_MAX_CHANNELS];
     int C, update_lag;
+    // a_smooth != 1 (level_solver_3d.py:262-311, 400-471): psi_smooth of the running iteration on the PADDED natural grid
+    // (Z+2, Y+2, X+2); nullptr: the constant-diffusion stencil.  The iterations then run one at a time (psi_smooth of
+    // iteration t is a function of the whole field of t-1), `t_base` = the iteration the launches belong to.
+    const double *Ps;
+    int t_base;
 };
 struct SorChainSched;
 long long launch_sor_verify(hipStream_t st, const VerifyArgs &a, const SorChainSched &sc);
+// psi_smooth of one iteration in the reference's arithmetic: D = increments as they stand (iteration t-1), Dm2 = those
+// of iteration t-2 (the padded arrays' ghost ring, set_boundary_3d of the previous iteration), all records of 3 on `sk`
+void launch_psi_smooth_verify(hipStream_t st, const Skew &sk, const double *U, const double *D, const double *Dm2, double a_smooth,
+                              double hx, double hy, double hz, double *Ps);
 void launch_median5_f64(hipStream_t st, const double *in, int Z, int Y, int X, double *out);
 template <typename TS, typename TD>
 void launch_cast(hipStream_t st, const TS *src, long long n, TD *dst);

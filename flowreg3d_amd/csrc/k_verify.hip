@@ -72,6 +72,28 @@ k_sor_verify(const VerifyArgs a, int tau, int t_lo, int nent, const SorEntry *__
     const double ax = a.ax, ay = a.ay, az = a.az;
     double denom_u = 0.0, denom_v = 0.0, denom_w = 0.0;
     double num_u = 0.0, num_v = 0.0, num_w = 0.0;
+    if (a.Ps) {
+        // level_solver_3d.py:400-471 (a_smooth != 1): z-, z+, y-, y+, x-, x+; the neighbour weight is the mean of psi_smooth
+        // at the voxel and at the neighbour (ghost positions included: psi_smooth lives on the padded grid)
+        const long long pn = X + 2, pm = (long long)(Y + 2) * pn;
+        const long long pc = (long long)(k + 1) * pm + (long long)(j + 1) * pn + (i + 1);
+        const double psc = a.Ps[pc];
+        auto term = [&](const Rec<double, 3> &Un, const Rec<double, 3> &Dn, double psn, double sc) {
+            const double tmp = 0.5 * (psc + psn) * sc;
+            num_u += tmp * (Un.v[0] + Dn.v[0] - U0.v[0]);
+            denom_u += tmp;
+            num_v += tmp * (Un.v[1] + Dn.v[1] - U0.v[1]);
+            denom_v += tmp;
+            num_w += tmp * (Un.v[2] + Dn.v[2] - U0.v[2]);
+            denom_w += tmp;
+        };
+        term(Ukm, Dkm, a.Ps[pc - pm], az);
+        term(Ukp, Dkp, a.Ps[pc + pm], az);
+        term(Ujm, Djm, a.Ps[pc - pn], ay);
+        term(Ujp, Djp, a.Ps[pc + pn], ay);
+        term(Uim, Dim, a.Ps[pc - 1], ax);
+        term(Uip, Dip, a.Ps[pc + 1], ax);
+    } else {
     // level_solver_3d.py:472-493 (a_smooth == 1), x then y then z, each sum left to right
     num_u += ax * (Uip.v[0] + Dip.v[0] + Uim.v[0] + Dim.v[0] - 2 * U0.v[0]);
     denom_u += 2 * ax;
@@ -91,10 +113,11 @@ k_sor_verify(const VerifyArgs a, int tau, int t_lo, int nent, const SorEntry *__
     denom_v += 2 * az;
     num_w += az * (Ukp.v[2] + Dkp.v[2] + Ukm.v[2] + Dkm.v[2] - 2 * U0.v[2]);
     denom_w += 2 * az;
+    }
 
     // psi_data (:356-377) from the increments of iteration t-1 on update iterations, the stored value otherwise;
     // ww = weight [* psi]
-    const bool upd = (t % a.update_lag) == 0;
+    const bool upd = ((t + a.t_base) % a.update_lag) == 0;
     double ww[FR3D_MAX_CHANNELS];
     double J12[FR3D_MAX_CHANNELS], J13[FR3D_MAX_CHANNELS], J23[FR3D_MAX_CHANNELS], J14[FR3D_MAX_CHANNELS],
         J24[FR3D_MAX_CHANNELS], J34[FR3D_MAX_CHANNELS];
@@ -153,6 +176,60 @@ long long launch_sor_verify(hipStream_t st, const VerifyArgs &a, const SorChainS
         launches++;
     }
     return launches;
+}
+
+// nonlinearity_smoothness_3d (level_solver_3d.py:262-311) on the padded grid, one thread per padded voxel: uu = u + du with
+// the padded arrays' contents as the reference has them when it evaluates psi_smooth of iteration t -- interior: the
+// increments of iteration t-1; ghost ring: the edge pad of the increments of iteration t-2 (set_boundary_3d ran before the
+// sweep of t-1) over the edge pad of u (add_boundary, core/optical_flow_3d.py:88) -- central differences with indices
+// clamped to the padded array, always divided by 2h, the nine squares summed in the reference's order, portable pow.
+__global__ void __launch_bounds__(256)
+k_psi_smooth_verify(const Skew sk, const double *__restrict__ U, const double *__restrict__ D, const double *__restrict__ Dm2,
+                    double a_smooth, double hx, double hy, double hz, double *__restrict__ Ps)
+{
+    const int Z = sk.Z, Y = sk.Y, X = sk.X;
+    const int P = Z + 2, M = Y + 2, N = X + 2;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)P * M * N) return;
+    const int i = (int)(e % N), j = (int)((e / N) % M), k = (int)(e / ((long long)N * M));
+    // uu at padded position (kk, jj, ii)
+    auto uu = [&](int kk, int jj, int ii, double (&o)[3]) {
+        const bool ghost = kk == 0 || kk == P - 1 || jj == 0 || jj == M - 1 || ii == 0 || ii == N - 1;
+        const int kc = kk - 1 < 0 ? 0 : (kk - 1 > Z - 1 ? Z - 1 : kk - 1);
+        const int jc = jj - 1 < 0 ? 0 : (jj - 1 > Y - 1 ? Y - 1 : jj - 1);
+        const int ic = ii - 1 < 0 ? 0 : (ii - 1 > X - 1 ? X - 1 : ii - 1);
+        const long long r = sk_index(sk, kc, jc, ic);
+        const Rec<double, 3> u = ldrec<double, 3>(U, r), d = ldrec<double, 3>(ghost ? Dm2 : D, r);
+        for (int c = 0; c < 3; c++) o[c] = u.v[c] + d.v[c];
+    };
+    const int ixm = i > 0 ? i - 1 : 0, ixp = i < N - 1 ? i + 1 : N - 1;
+    const int jym = j > 0 ? j - 1 : 0, jyp = j < M - 1 ? j + 1 : M - 1;
+    const int kzm = k > 0 ? k - 1 : 0, kzp = k < P - 1 ? k + 1 : P - 1;
+    double xp[3], xm[3], yp[3], ym[3], zp[3], zm[3];
+    uu(k, j, ixp, xp); uu(k, j, ixm, xm);
+    uu(k, jyp, i, yp); uu(k, jym, i, ym);
+    uu(kzp, j, i, zp); uu(kzm, j, i, zm);
+    double g = 0.0;
+    bool first = true;
+    for (int c = 0; c < 3; c++) {
+        const double dx = (xp[c] - xm[c]) / (2 * hx);
+        const double dy = (yp[c] - ym[c]) / (2 * hy);
+        const double dz = (zp[c] - zm[c]) / (2 * hz);
+        if (first) { g = dx * dx; first = false; }
+        else g = g + dx * dx;
+        g = g + dy * dy;
+        g = g + dz * dz;
+    }
+    if (g < 0.0) g = 0.0;
+    Ps[e] = a_smooth * fr3d_ppow(g + 1e-5, a_smooth - 1.0);
+}
+
+void launch_psi_smooth_verify(hipStream_t st, const Skew &sk, const double *U, const double *D, const double *Dm2, double a_smooth,
+                              double hx, double hy, double hz, double *Ps)
+{
+    const long long n = (long long)(sk.Z + 2) * (sk.Y + 2) * (sk.X + 2);
+    hipLaunchKernelGGL(k_psi_smooth_verify, dim3(cdiv(n, 256)), dim3(256), 0, st, sk, U, D, Dm2, a_smooth, hx, hy, hz, Ps);
+    FR3D_LAUNCH_CHECK();
 }
 
 // ---- fp64 tail of a level ---------------------------------------------------------------------------------------

@@ -10,7 +10,8 @@ import pytest
 
 from conftest import GOLDEN
 
-CASES = [c for c in ("cfg2", "cfg2_asmooth05", "cfg3", "cfg5") if os.path.exists(os.path.join(GOLDEN, f"fullsize_{c}.npz"))]
+CASES = [c for c in ("cfg2", "cfg2_asmooth05", "cfg3", "cfg5", "thr_160x176x176", "thr_200")
+         if os.path.exists(os.path.join(GOLDEN, f"fullsize_{c}.npz"))]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -30,7 +31,8 @@ def test_fixture_is_well_formed(case):
 
 
 def test_all_cases_are_committed():
-    assert CASES == ["cfg2", "cfg2_asmooth05", "cfg3", "cfg5"]
+    # (thr_*: volumes just above the 2^22-voxel switch of FR3D_SOLVER_AUTO from fp32 to packed solver storage)
+    assert CASES == ["cfg2", "cfg2_asmooth05", "cfg3", "cfg5", "thr_160x176x176", "thr_200"]
     meta = json.loads(bytes(np.load(os.path.join(GOLDEN, "fullsize_cfg2_asmooth05.npz"))["meta"]).decode())
     assert meta["params"]["a_smooth"] == 0.5 and meta["params"]["levels"] == 4
 

@@ -136,7 +136,7 @@ def _measure(case, solver_fp64=None):
 
 
 @pytest.mark.parametrize("case", ["cfg2_recipe", "cfg2_recipe_s135", "cfg2", "cfg2_asmooth05", "cfg3_recipe", "cfg3", "cfg5",
-                                  "cfg5_levels8"])
+                                  "cfg5_levels8", "thr_160x176x176", "thr_200"])
 def test_fullsize_flow_matches_oracle_sample(hip, case):
     e, msg = _measure(case)
     tol = TOL_MEAN

@@ -40,6 +40,12 @@ def _same(a, b, label):
     ((16, 30, 30), 3, dict(update_lag=1, iterations=12)),        # psi update on every iteration
     ((40, 24, 26), 1, dict(min_level=1, levels=4)),              # final resample back to full size
     ((18, 22, 70), 1, dict(a_data=1.0, eta=0.7)),                # a_data = 1: psi is not used
+    # the psi_smooth branch (level_solver_3d.py:262-311, 400-471; get_displacement's own default a_smooth = 0.5): psi_smooth on
+    # the padded grid from the increments of t-1 (interior) and t-2 (ghost ring), psi-weighted stencil in the reference's order
+    ((20, 28, 30), 1, dict(a_smooth=0.5)),
+    ((19, 33, 26), 2, dict(a_smooth=0.5, a_data=[0.45, 0.6], update_lag=3, iterations=17)),
+    ((7, 9, 40), 1, dict(a_smooth=0.8, levels=2)),                # thin volume: every voxel touches a face
+    ((24, 26, 22), 1, dict(a_smooth=0.5, min_level=1, levels=4, eta=0.75)),
 ])
 def test_verify_mode_is_bit_identical_to_the_ppow_oracle(hip, ppow_oracle, shape, ch, kw):
     from flowreg3d_amd.synthetic import make_pair
@@ -75,10 +81,11 @@ def test_shipped_modes_differ_from_the_verified_path_by_rounding_only(hip):
         assert d.mean() < tol, (mode, d.mean())
 
 
-@pytest.mark.parametrize("case", ["cfg5", "cfg3"])
+@pytest.mark.parametrize("case", ["cfg5", "cfg3", "cfg2_asmooth05"])
 def test_fullsize_verify_mode_is_bit_identical_to_the_ppow_oracle_sample(hip, case):
-    """BASELINE configurations 5 and 3 AT FULL SIZE: the verification mode against the `ppow` oracle's committed sample
-    (float64 lattice of every 8th voxel + central 32^3 block), bit for bit."""
+    """BASELINE configurations 5 and 3 AT FULL SIZE, and config 2's volume with a_smooth = 0.5 (the psi_smooth branch): the
+    verification mode against the `ppow` oracle's committed sample (float64 lattice of every 8th voxel + central 32^3
+    block), bit for bit."""
     from flowreg3d_amd.synthetic import fullsize_case
     path = os.path.join(GOLDEN, f"fullsize_{case}_ppow.npz")
     if not os.path.exists(path):
