@@ -631,7 +631,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         if (p.a_smooth == 1.0) {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
             long long n;
-            if (use_window_sweep(p, C, lz, ly, lx) && sor_win_fits(sk)) {
+            if (use_window_sweep(p, C, lz, ly, lx) && sor_win_fits(sk) && sor_win_storage<S>()) {
                 // window sweep (k_sor_win.hip): the exports of the slots before the last one, laid out like d
                 WinArgs<S> wa;
                 std::memset(&wa, 0, sizeof(wa));

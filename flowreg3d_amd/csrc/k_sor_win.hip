@@ -25,7 +25,7 @@ struct WinTabLds {
 static size_t win_table_bytes(const Skew &sk) { return (size_t)(sk.S + 2) * 8 + (size_t)(sk.X + sk.Y + 2) * 4; }
 
 template <typename R, typename S, int C, int W, bool BUILD>
-__global__ void __launch_bounds__(WIN_NT)
+__global__ void __launch_bounds__(WIN_WMAX * WIN_NL)
 k_sor_win(const WinArgs<S> wa, const WinTile *__restrict__ tiles)
 {
     using Th = WinThread<R, S, C, W, BUILD, WinTabLds>;
@@ -40,7 +40,6 @@ k_sor_win(const WinArgs<S> wa, const WinTile *__restrict__ tiles)
     for (int n = tid; n < sk.X + sk.Y + 2; n += WIN_NT) cpl[n] = sk.cp[n];
     Th th;
     th.init(wa, tl, (int)blockIdx.y, tid, 0, 0);
-    th.init_lds(lds);
     int s0, s1;
     Th::step_range(sk, tl, s0, s1);
     const WinNoHook hk;
@@ -72,17 +71,27 @@ void free_win_schedule(WinSched &ws)
 }
 
 bool sor_win_supports(int C) { return C >= 1 && C <= 2; }
-// the level's row-start tables must fit beside the exchange buffers in LDS (axes up to ~2000 voxels)
-bool sor_win_fits(const Skew &sk) { return sk.pb != nullptr && win_table_bytes(sk) <= 48 * 1024; }
+template <typename S> bool sor_win_storage() { return !std::is_same<S, double>::value; }
+template bool sor_win_storage<float>();
+template bool sor_win_storage<double>();
+template bool sor_win_storage<pk42>();
+// the level's row-start tables must fit beside the exchange buffers in LDS
+bool sor_win_fits(const Skew &sk) { return sk.pb != nullptr && win_table_bytes(sk) <= 24 * 1024; }
 
 template <typename R, typename S, int C>
 static void launch_win_step(hipStream_t st, const WinArgs<S> &wa, const WinTile *tiles, int count, bool build)
 {
     if (count <= 0) return;
-    const dim3 grid(count, wa.a.nvol > 0 ? wa.a.nvol : 1), block(WIN_NT);
-    if (build) hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX, true>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
-    else hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX, false>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
-    FR3D_LAUNCH_CHECK();
+    if constexpr (std::is_same<S, double>::value) {
+        // the hand-off records of a 12 x 16 tile in fp64 (2 x 4 x 72 B per line) do not fit the 160 KiB of LDS beside the
+        // outputs; fp64 storage takes the plane sweep
+        throw Error("window sweep: fp64 solver storage is not built (LDS)");
+    } else {
+        const dim3 grid(count, wa.a.nvol > 0 ? wa.a.nvol : 1), block(WIN_NT);
+        if (build) hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX, true>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
+        else hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX, false>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
+        FR3D_LAUNCH_CHECK();
+    }
 }
 
 template <typename S>

@@ -131,18 +131,16 @@ static int run(int Z, int Y, int X, int T, int lag, unsigned seed)
     auto run_tile = [&](auto build_tag, const WinTile &tl, int win, int l, int n) {
         constexpr bool BUILD = decltype(build_tag)::value;
         using Th = WinThread<R, S, C, W, BUILD, WinTabPtr, EmuHook>;
-        static std::vector<Th> th(WIN_NT);
+        constexpr int NT = W * WIN_NL;
+        static std::vector<Th> th(NT);
         static typename Th::Lds lds;
         EmuHook hk{sh, l, n};
         int s0, s1;
         Th::step_range(sk, tl, s0, s1);
         memset(&lds, 0xff, sizeof(lds));  // stale LDS content must not matter
-        for (int tid = 0; tid < WIN_NT; tid++) {
-            th[tid].init(wa, tl, 0, tid, win, sc.windows[win].win_build);
-            th[tid].init_lds(lds);
-        }
+        for (int tid = 0; tid < NT; tid++) th[tid].init(wa, tl, 0, tid, win, sc.windows[win].win_build);
         for (int s = s0 - WIN_LEAD; s <= s1; s++) {
-            for (int tid = 0; tid < WIN_NT; tid++) th[tid].step(wa, tb, s, lds, hk);
+            for (int tid = 0; tid < NT; tid++) th[tid].step(wa, tb, s, lds, hk);
             steps++;
         }
         wg++;
