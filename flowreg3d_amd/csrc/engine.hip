@@ -509,7 +509,7 @@ static void build_ref_pyramid(Engine &e, const std::vector<Level> &lv, const flo
     }
 }
 
-static bool use_window_sweep(const fr3d_params &p, int C, int lz, int ly, int lx);
+static bool use_window_sweep(const fr3d_params &p, int C, bool fp64_storage);
 
 // Solve `nb` volumes against the same reference pyramid in lock step: every stage before and after
 // the solver runs per volume, the SOR launches advance all nb volumes at once (the launch count per
@@ -631,7 +631,7 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
         if (p.a_smooth == 1.0) {
             Span sp(e, FR3D_K_SOR, 0, 0, 0);
             long long n;
-            if (use_window_sweep(p, C, lz, ly, lx) && sor_win_fits(sk) && sor_win_storage<S>()) {
+            if (use_window_sweep(p, C, std::is_same<S, double>::value) && sor_win_fits(sk) && sor_win_storage<S>(C)) {
                 // window sweep (k_sor_win.hip): the exports of the slots before the last one, laid out like d
                 WinArgs<S> wa;
                 std::memset(&wa, 0, sizeof(wa));
@@ -964,17 +964,20 @@ static void get_displacement_verify(Engine &e, const fr3d_params &p, const std::
 }
 
 // Which kernel runs the a_smooth == 1 sweep of a level (fr3d_params.solver_sweep; env FR3D_SWEEP=planes|window
-// overrides an automatic choice).  Both produce the same bits.
-static bool use_window_sweep(const fr3d_params &p, int C, int lz, int ly, int lx)
+// overrides an automatic choice).  Both produce the same bits.  FR3D_SWEEP_AUTO is the plane sweep everywhere: the
+// window sweep (k_sor_win.hip) is bound by its instruction stream (~490 per update) and measured behind it in every
+// storage format but fp64, where the two are level (256^3 batch 8, same box: 129 against 132 ms of sweeps per volume;
+// fp32 storage 101 against 65, packed 171 against 88 -- DESIGN.md section 4, round 4).
+static bool use_window_sweep(const fr3d_params &p, int C, bool fp64_storage)
 {
-    if (!sor_win_supports(C) || p.iterations <= 0) return false;
+    (void)fp64_storage;
+    if (!sor_win_supports(C) || p.iterations <= 0 || p.a_smooth != 1.0) return false;
     int sw = p.solver_sweep;
     if (sw == FR3D_SWEEP_AUTO) {
         static const char *env = getenv("FR3D_SWEEP");
         if (env && !strcmp(env, "window")) sw = FR3D_SWEEP_WINDOW;
         else if (env && !strcmp(env, "planes")) sw = FR3D_SWEEP_PLANES;
     }
-    (void)lz; (void)ly; (void)lx;
     return sw == FR3D_SWEEP_WINDOW;
 }
 
@@ -1023,6 +1026,7 @@ static void get_displacement_core(Engine &e, const fr3d_params &p_in, const std:
 static int g_batch_hint = 0;  // fr3d_set_batch()
 static bool g_fast_path = true;  // a_smooth == 1 of the call in progress (the psi_smooth path holds 13 more values per voxel)
 static double g_storage_bytes = 4.0;  // bytes per stored solver value of the call in progress
+static bool g_window = false;         // the call in progress runs the window sweep (its export arrays count in the budget)
 
 // fr3d_set_batch(), else FR3D_BATCH, else 8
 static int batch_wanted()
@@ -1033,7 +1037,7 @@ static int batch_wanted()
 
 // Bytes one volume of a lock-step batch holds on the finest level with `bytes` per stored solver value, and the HBM
 // the solver slabs may occupy right now.
-static double solver_bytes_per_volume(const std::vector<Level> &lv, int C, double bytes, bool fast_path)
+static double solver_bytes_per_volume(const std::vector<Level> &lv, int C, double bytes, bool fast_path, bool window = false)
 {
     const Level &F = lv.back();
     std::vector<long long> pb;
@@ -1041,7 +1045,8 @@ static double solver_bytes_per_volume(const std::vector<Level> &lv, int C, doubl
     const double total = (double)make_compact_tables(F.z, F.y, F.x, pb, cp);  // packed rows: 1.1-1.3x the voxel count
     const double nfin = (double)F.z * F.y * F.x;
     // skewed solver slabs + the level flows of a volume (two generations of u,v,w)
-    return total * bytes * (12.0 * C + 9.0 + 6.0 + (fast_path ? 0.0 : 13.0)) + nfin * 4.0 * 9.0;
+    // (the window sweep adds the exports of its first WIN_WMAX - 1 slots, records of 3)
+    return total * bytes * (12.0 * C + 9.0 + 6.0 + (fast_path ? 0.0 : 13.0) + (window ? 3.0 * (WIN_WMAX - 1) : 0.0)) + nfin * 4.0 * 9.0;
 }
 // `lanes`: engine lanes the call will run on -- each holds its own per-level scratch
 static double solver_budget(const std::vector<Level> &lv, int C, int lanes = 1)
@@ -1096,7 +1101,7 @@ static int pick_batch(int T, const std::vector<Level> &lv, int C, int lanes = 1)
     int want = batch_wanted();
     if (want > T) want = T;
     if (want < 1) want = 1;
-    const double per_vol = solver_bytes_per_volume(lv, C, g_storage_bytes, g_fast_path);
+    const double per_vol = solver_bytes_per_volume(lv, C, g_storage_bytes, g_fast_path, g_window);
     const double budget = solver_budget(lv, C, lanes);
     if (budget > 0)
         while (want > 1 && per_vol * want > budget) want--;
@@ -1229,6 +1234,7 @@ static void process_batch_dev(const fr3d_params *p, const float *batch_proc, con
     {
         const int m = resolve_mode(*p, C, Z, Y, X, lv);
         g_storage_bytes = m == 2 ? 8.0 : (m == 3 ? 16.0 / 3.0 : 4.0);
+        g_window = use_window_sweep(*p, C, m == 2) && (m != 2 || C == 1);
     }
     g_fast_path = p->a_smooth == 1.0;
     int B = T > 0 ? pick_batch(T, lv, C) : 1;

@@ -394,7 +394,7 @@ struct WinSched {
 WinSched build_win_schedule(const Skew &sk, int iterations, int update_lag);
 void free_win_schedule(WinSched &ws);
 bool sor_win_supports(int C);
-template <typename S> bool sor_win_storage();  // storage formats the window kernel is built for
+template <typename S> bool sor_win_storage(int C);  // storage formats / channel counts the window kernel is built for
 bool sor_win_fits(const Skew &sk);
 template <typename S>
 long long launch_sor_win(hipStream_t st, const WinArgs<S> &wa, bool fp64, const WinSched &ws);

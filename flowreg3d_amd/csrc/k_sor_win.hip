@@ -2,11 +2,11 @@
 // The algorithm, the per-thread state and the step function are in k_sor_win_core.h (shared with the CPU emulator
 // tools/emu/sor_win_emu.hip); reference: core/level_solver_3d.py:314-546.
 //
-// One workgroup = 256 threads = one tile of 16 x 16 lines for one psi window, one wave per SIMD: a thread carries the
-// window's whole per-line state in registers (increment history of every slot, the frozen systems on their way from
-// slot to slot, the prefetched operands of the next step: ~300 VGPRs), so the occupancy is one wave per SIMD by
-// design and latency is hidden by the five independent slot updates of a step and by prefetching every global
-// operand one step ahead.  LDS: the slots' outputs of the last two steps (72 KiB with fp64 values), one barrier per step.
+// One workgroup = WIN_WMAX x WIN_NL threads = one tile of WIN_BK x WIN_BJ lines for one psi window: thread (q, line)
+// runs slot q (iteration t0 + q) of its line and hands the increments and the frozen system on to slot q + 1 through
+// LDS (double-buffered by step parity, one barrier per step); only slot 0 reads the operands from HBM, only the last
+// slot writes the increments back.  HBM traffic per update falls to about a W-th of the plane sweep's; the kernel is
+// bound by its instruction stream instead.
 #include <cstdio>
 #include <cstdlib>
 
@@ -71,10 +71,10 @@ void free_win_schedule(WinSched &ws)
 }
 
 bool sor_win_supports(int C) { return C >= 1 && C <= 2; }
-template <typename S> bool sor_win_storage() { return !std::is_same<S, double>::value; }
-template bool sor_win_storage<float>();
-template bool sor_win_storage<double>();
-template bool sor_win_storage<pk42>();
+template <typename S> bool sor_win_storage(int C) { return !std::is_same<S, double>::value || C == 1; }
+template bool sor_win_storage<float>(int);
+template bool sor_win_storage<double>(int);
+template bool sor_win_storage<pk42>(int);
 // the level's row-start tables must fit beside the exchange buffers in LDS
 bool sor_win_fits(const Skew &sk) { return sk.pb != nullptr && win_table_bytes(sk) <= 24 * 1024; }
 
@@ -82,11 +82,7 @@ template <typename R, typename S, int C>
 static void launch_win_step(hipStream_t st, const WinArgs<S> &wa, const WinTile *tiles, int count, bool build)
 {
     if (count <= 0) return;
-    if constexpr (std::is_same<S, double>::value) {
-        // the hand-off records of a 12 x 16 tile in fp64 (2 x 4 x 72 B per line) do not fit the 160 KiB of LDS beside the
-        // outputs; fp64 storage takes the plane sweep
-        throw Error("window sweep: fp64 solver storage is not built (LDS)");
-    } else {
+    {
         const dim3 grid(count, wa.a.nvol > 0 ? wa.a.nvol : 1), block(WIN_NT);
         if (build) hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX, true>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
         else hipLaunchKernelGGL((k_sor_win<R, S, C, WIN_WMAX, false>), grid, block, win_table_bytes(wa.a.sk), st, wa, tiles);
@@ -111,9 +107,13 @@ long long launch_sor_win(hipStream_t st, const WinArgs<S> &wa, bool fp64, const 
             if (wa.a.C == 1) {
                 if (r64) launch_win_step<double, S, 1>(st, wa, tiles, n, part == 0);
                 else if constexpr (!Sto<S>::wide) launch_win_step<float, S, 1>(st, wa, tiles, n, part == 0);
-            } else {
+            } else if constexpr (!std::is_same<S, double>::value) {
                 if (r64) launch_win_step<double, S, 2>(st, wa, tiles, n, part == 0);
                 else if constexpr (!Sto<S>::wide) launch_win_step<float, S, 2>(st, wa, tiles, n, part == 0);
+            } else {
+                // not built: 165+ VGPRs for one channel already (the build role would spill), and several channels
+                // default to the plane sweep with fp64 storage anyway
+                throw Error("window sweep: two channels with fp64 solver storage are not built (LDS)");
             }
             launches++;
         }

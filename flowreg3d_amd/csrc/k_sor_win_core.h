@@ -37,11 +37,13 @@
 // storage format after every update): tests/test_gpu_sor_window.py.
 #pragma once
 
+#include <cstring>
+
 #include "k_sor_core.h"
 
 namespace fr3d {
 
-#define WIN_BK 12    // lines of a tile in k
+#define WIN_BK 8     // lines of a tile in k
 #define WIN_BJ 16    // lines of a tile in j
 #define WIN_NL (WIN_BK * WIN_BJ)    // lines of a tile = threads per slot (a multiple of 64: a wave is one slot)
 #define WIN_WMAX 5   // slots (iterations) of a window kept on chip
@@ -65,11 +67,17 @@ struct WinArgs {
 // LDS image of one workgroup (double-buffered by step parity; one barrier per step):
 //  * O[p][q][c][line]: outputs of the slots (index q + 1) and of the loader (index 0: d of the slot-0 line, two voxels
 //    ahead of slot 0) in the steps of parity p;
-//  * H[p][q][w][line]: the frozen system handed TO slot q (q >= 1) by slot q-1, raw storage words.
-template <typename V, int W, int NWH>
+//  * H[p][q][w][line]: the frozen system handed to slot q + 1 by slot q, raw storage words.
+// Slot 0's HBM operands are NOT staged here: requesting them a step ahead by the gfx950 async global -> LDS copy
+// (global_load_lds; lane-linear destinations, 16- and 4-byte chunks -- the 12-byte form faulted on this pool, gpurun r04r)
+// or by register loads parked with ds_write both lost against plain same-step loads (numbers at the loads in step_t).
+template <typename S, int C, int W, bool BUILD>
 struct WinLds {
+    using V = typename Sto<S>::val;
+    using WT = typename StoWt<S>::type;
+    static constexpr int NWH = sizeof(RawRec<S, 9>) / 4;
     V O[2][W + 1][3][WIN_NL];
-    unsigned H[2][W > 1 ? W - 1 : 1][NWH][WIN_NL];  // index q - 1
+    unsigned H[2][W > 1 ? W - 1 : 1][NWH][WIN_NL];
 };
 
 // Row-start tables of the compact skewed layout (Skew::pb / cp) as the kernel sees them: the device keeps copies in
@@ -111,11 +119,10 @@ struct WinThread {
     static_assert(W >= 1 && W <= WIN_WMAX, "window slots");
     static_assert(C >= 1, "channel count is a template parameter");
     static_assert(WIN_NL % 64 == 0 && W - 1 < WIN_BK && W - 1 < WIN_BJ, "tile shape");
-    static constexpr int NWH = sizeof(RawRec<S, 9>) / 4;  // words of a system record
-    using Lds = WinLds<V, W, NWH>;
+    using Lds = WinLds<S, C, W, BUILD>;
 
     // ---- constant per thread ----
-    int q, a, b, line, tid;
+    int q, a, b, line, tid, lane0_line;
     int K, J, nsl;
     bool storeM;
     bool spa, spb;  // this thread's line is the bottom of its slot's range in a / in b: imports instead of neighbours
@@ -127,7 +134,7 @@ struct WinThread {
     // ---- state ----
     V xp_prev[3];    // last step's i+1 neighbour = this step's own old value
     V out_prev[3];   // last step's output = this step's i-1 neighbour
-    RawRec<S, 9> Hcur;  // the system of this step's voxel (slots >= 1: read from LDS one step ago)
+    RawRec<S, 9> Hcur;  // slots >= 1: the system of this step's voxel (read from LDS at the end of the previous step)
 
     FR3D_HD static int kline(int K, int a, int q) { return K * WIN_BK + a - (a >= WIN_BK - q ? WIN_BK : 0); }
     FR3D_HD static int jline(int J, int b, int q) { return J * WIN_BJ + b - (b >= WIN_BJ - q ? WIN_BJ : 0); }
@@ -152,13 +159,27 @@ struct WinThread {
         for (int n = 0; n < (int)(sizeof(T) / 4); n++) x.w[n] = src[n][line];
         return __builtin_bit_cast(T, x);
     }
+    FR3D_HD static RawRec<S, 9> encode9(const Rec<S, 9> &r)
+    {
+        RawRec<S, 9> raw;
+        if constexpr (std::is_same<S, pk42>::value) {
+            alignas(16) S tmp[12];
+            strec<S, 9>(tmp, 0, r);
+            raw = *reinterpret_cast<const RawRec<S, 9> *>(tmp);
+        } else {
+#pragma unroll
+            for (int n = 0; n < 9; n++) raw.w[n] = r.v[n];
+        }
+        return raw;
+    }
 
     FR3D_HD void init(const WinArgs<S> &wa, const WinTile &tl, int vol, int tid_, int win_, int win_build_)
     {
         const SorArgsT<S> &A_ = wa.a;
         tid = tid_;
-        q = tid / WIN_NL;
+        q = tid / WIN_NL;  // slot-major: a wave is one slot
         line = tid % WIN_NL;
+        lane0_line = line - (tid & 63);
         a = line / WIN_BJ;
         b = line % WIN_BJ;
         K = tl.K; J = tl.J;
@@ -177,8 +198,8 @@ struct WinThread {
     }
 
     // first step in which any slot of this tile has a voxel, and the last one; the kernel starts WIN_LEAD steps
-    // earlier, with every slot still idle, so that the pipelines (loader, own-old values, systems) fill through the
-    // ordinary step code
+    // earlier, with every slot still idle, so that the pipelines (requests, loader, own-old values, systems) fill
+    // through the ordinary step code
     FR3D_HD static void step_range(const Skew &sk, const WinTile &tl, int &s_first, int &s_last)
     {
         const int nsl = tl.info & 0xff;
@@ -201,8 +222,10 @@ struct WinThread {
     }
 
     // step s of this thread's slot: read the LDS image of step s-1 (parity pp), compute, publish in the image of step s.
+    // SLOT0 = this thread is a slot-0 thread (a separate code path: the two roles need different registers).
     // The caller puts a barrier behind it.
-    FR3D_HD void step(const WinArgs<S> &wa, const Tab &tb, int s, Lds &lds, const Hook &hk)
+    template <bool SLOT0>
+    FR3D_HD void step_t(const WinArgs<S> &wa, const Tab &tb, int s, Lds &lds, const Hook &hk)
     {
         const SorArgsT<S> &A_ = wa.a;
         const int pp = (s - 1) & 1, pc = s & 1;
@@ -211,18 +234,21 @@ struct WinThread {
         const bool active = lok && i >= 0 && i < X;
         const int t_am = ((a + WIN_BK - 1) % WIN_BK) * WIN_BJ + b, t_ap = ((a + 1) % WIN_BK) * WIN_BJ + b;
         const int t_bm = a * WIN_BJ + (b + WIN_BJ - 1) % WIN_BJ, t_bp = a * WIN_BJ + (b + 1) % WIN_BJ;
-        const bool sw = q >= 1 && (spa || spb);  // the line was taken over from another tile in this slot
 
-        // ---- requests to HBM (used further down in this step: the other waves of the SIMD cover the latency) ----
-        Rec<S, 3> Lrec, NBa, NBb, SWx, SXa, SXb, TOPa, TOPb;
-        RawRec<S, 9> SM;
-        RawRec<S, 12> fr[C];
-        WT wt[C];
-        RawRec<S, 3> lr;
-        RawRec<S, 9> mx;
-        if (q == 0) {
+        V own[3], xp[3], xm[3], yp[3], ym[3], zp[3], zm[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) own[c] = xp_prev[c];
+
+        // ---- the frozen system of this step's voxel ----
+        Rec<S, 9> mr;
+        Rec<S, 3> Lrec;
+        if constexpr (SLOT0) {
+            // Same-step loads (clamped, unconditional).  Two ways of requesting them one step early were measured and
+            // lost at 256^3 fp64 storage (107 ms of sweeps per volume with these loads): LDS-DMA into a staging
+            // buffer (14 wave-instructions of 60-185 issue cycles each: 135 ms) and register loads parked in LDS at
+            // the end of the step (38 more live registers in this role, 132 B of scratch: 208 ms).
             const int kc = clampi(k, 0, Z - 1), jc = clampi(j, 0, Y - 1);
-            {   // the loader: d of this line two voxels ahead
+            {   // the loader: d of this line two voxels ahead of slot 0
                 const int il = i + 2;
                 const long long e = win_index(tb, X, kc, jc, clampi(il, 0, X - 1));
                 if (lok && il >= 0 && il < X) hk.rd(WIN_ARR_D, e, win - 1);
@@ -230,52 +256,26 @@ struct WinThread {
             }
             const long long e = win_index(tb, X, kc, jc, clampi(i, 0, X - 1));
             if constexpr (BUILD) {
+                SorAcc<R> acc;
 #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    fr[c] = ldraw<S, 12>(A_.A[c] + vA, e);
-                    wt[c] = A_.weight[c][e];
+                for (int c = 0; c < C; c++)
+                    sor_accum_channel<R, S>(ldrec<S, 12>(A_.A[c] + vA, e), (double)A_.weight[c][e], A_.a_data[c], (R)own[0],
+                                            (R)own[1], (R)own[2], acc);
+                mr = sor_finish_system<R, S>(acc, ldrec<S, 3>(A_.L + vL, e));
+                // lines that another tile takes over later need the record in memory
+                if (active && (storeM || a >= WIN_BK - W + 1 || b >= WIN_BJ - W + 1)) {
+                    hk.wr(WIN_ARR_M, e, win);
+                    strec<S, 9>(A_.M + vM, e, mr);
                 }
-                lr = ldraw<S, 3>(A_.L + vL, e);
             } else {
                 if (active) hk.rd(WIN_ARR_M, e, win_build);
-                mx = ldraw<S, 9>(A_.M + vM, e);
-            }
-            // top row / column of slot 0: the +1 neighbour belongs to the tile above; its value of the previous window is in d
-            if (active && a == WIN_BK - 1 && k + 1 < Z) {
-                const long long en = win_index(tb, X, k + 1, j, i);
-                hk.rd(WIN_ARR_D, en, win - 1);
-                TOPa = ldrec<S, 3>(A_.d + vD, en);
-            }
-            if (active && b == WIN_BJ - 1 && j + 1 < Y) {
-                const long long en = win_index(tb, X, k, j + 1, i);
-                hk.rd(WIN_ARR_D, en, win - 1);
-                TOPb = ldrec<S, 3>(A_.d + vD, en);
-            }
-        }
-        if (lok && (spa || spb)) {
-            // -1 neighbours across the tile edge: this window's slot-q value of the line below
-            if (active && spa && k > 0) NBa = import3(wa, tb, q, k - 1, j, i, hk);
-            if (active && spb && j > 0) NBb = import3(wa, tb, q, k, j - 1, i, hk);
-            if (q >= 1) {
-                // the line's slot q-1 values come from the exports of the tile it is taken over from: its i+1 neighbour
-                // (one step later its own old value), its frozen system, and the +1 neighbour in the other direction
-                // (on the same exported row / column)
-                if (i + 1 >= 0 && i + 1 < X) SWx = import3(wa, tb, q - 1, k, j, i + 1, hk);
-                if (active) {
-                    const long long e = win_index(tb, X, k, j, i);
-                    hk.rd(WIN_ARR_M, e, win_build);
-                    SM = ldraw<S, 9>(A_.M + vM, e);
-                    if (spa && j + 1 < Y) SXa = import3(wa, tb, q - 1, k, j + 1, i, hk);
-                    if (spb && k + 1 < Z) SXb = import3(wa, tb, q - 1, k + 1, j, i, hk);
-                }
+                mr = ldrec<S, 9>(A_.M + vM, e);
             }
         }
 
         // ---- the LDS image of step s-1 ----
-        V own[3], xp[3], xm[3], yp[3], ym[3], zp[3], zm[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            own[c] = xp_prev[c];
             xm[c] = out_prev[c];
             xp[c] = lds.O[pp][q][c][line];          // this line in slot q-1 (q = 0: the loader), one voxel ahead
             zm[c] = lds.O[pp][q + 1][c][t_am];       // -1 neighbours: this slot
@@ -283,63 +283,63 @@ struct WinThread {
             zp[c] = lds.O[pp][q][c][t_ap];           // +1 neighbours: slot q-1
             yp[c] = lds.O[pp][q][c][t_bp];
         }
-        // the system of the NEXT step's voxel, handed over by slot q-1 in step s-1
-        RawRec<S, 9> Hnext = RawRec<S, 9>{};
-        if (q >= 1) Hnext = words_get<RawRec<S, 9>>(lds.H[pp][q - 1]);
 
-        // ---- what comes from other tiles instead ----
-        if (spa || spb || q == 0) {
+        // ---- what comes from other tiles instead (straight into the neighbour values: no registers of their own) ----
+        auto take = [&](V (&dst)[3], const Rec<S, 3> &r) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                if (sw) xp[c] = SWx.v[c];
-                if (spa) zm[c] = NBa.v[c];
-                if (spb) ym[c] = NBb.v[c];
-                if (q == 0) {
-                    if (a == WIN_BK - 1) zp[c] = TOPa.v[c];
-                    if (b == WIN_BJ - 1) yp[c] = TOPb.v[c];
-                } else {
-                    if (spa) yp[c] = SXa.v[c];
-                    if (spb) zp[c] = SXb.v[c];
+            for (int c = 0; c < 3; c++) dst[c] = r.v[c];
+        };
+        if constexpr (SLOT0) {
+            if (active) {
+                // top row / column of slot 0: the +1 neighbour belongs to the tile above; its value of the previous window is in d
+                if (a == WIN_BK - 1 && k + 1 < Z) {
+                    const long long en = win_index(tb, X, k + 1, j, i);
+                    hk.rd(WIN_ARR_D, en, win - 1);
+                    take(zp, ldrec<S, 3>(A_.d + vD, en));
+                }
+                if (b == WIN_BJ - 1 && j + 1 < Y) {
+                    const long long en = win_index(tb, X, k, j + 1, i);
+                    hk.rd(WIN_ARR_D, en, win - 1);
+                    take(yp, ldrec<S, 3>(A_.d + vD, en));
                 }
             }
         }
+        if (lok && (spa || spb)) {
+            // -1 neighbours across the tile edge: this window's slot-q value of the line below
+            if (active && spa && k > 0) take(zm, import3(wa, tb, q, k - 1, j, i, hk));
+            if (active && spb && j > 0) take(ym, import3(wa, tb, q, k, j - 1, i, hk));
+            if constexpr (!SLOT0) {
+                // the line's slot q-1 values come from the exports of the tile it is taken over from: its i+1 neighbour
+                // (one step later its own old value), its frozen system, and the +1 neighbour in the other direction
+                // (on the same exported row / column)
+                if (i + 1 >= 0 && i + 1 < X) take(xp, import3(wa, tb, q - 1, k, j, i + 1, hk));
+                if (active) {
+                    const long long e = win_index(tb, X, k, j, i);
+                    hk.rd(WIN_ARR_M, e, win_build);
+                    Hcur = ldraw<S, 9>(A_.M + vM, e);
+                    if (spa && j + 1 < Y) take(yp, import3(wa, tb, q - 1, k, j + 1, i, hk));
+                    if (spb && k + 1 < Z) take(zp, import3(wa, tb, q - 1, k + 1, j, i, hk));
+                }
+            }
+        }
+        if constexpr (!SLOT0) mr = Hcur.dec();  // handed over by slot q-1, or just imported with the line
+
         // Neumann ghosts (set_boundary_3d :246-259): a missing neighbour is the voxel's own old value
         // (xp keeps the neighbour's value for the next step's own old value; the ghosted copy is xpg)
+        V xpg[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) xpg[c] = xp[c];
         const bool ghost = i <= 0 || i >= X - 1 || j == 0 || j == Y - 1 || k == 0 || k == Z - 1;
         if (WIN_ANY(ghost)) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
+                xpg[c] = sel(i < X - 1, xp[c], own[c]);
                 xm[c] = sel(i > 0, xm[c], own[c]);
                 zm[c] = sel(k > 0, zm[c], own[c]);
                 ym[c] = sel(j > 0, ym[c], own[c]);
                 zp[c] = sel(k < Z - 1, zp[c], own[c]);
                 yp[c] = sel(j < Y - 1, yp[c], own[c]);
             }
-        }
-        V xpg[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) xpg[c] = sel(i < X - 1, xp[c], own[c]);
-
-        // ---- the frozen system ----
-        Rec<S, 9> mr;
-        if (q == 0) {
-            if constexpr (BUILD) {
-                SorAcc<R> acc;
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    sor_accum_channel<R, S>(fr[c].dec(), (double)wt[c], A_.a_data[c], (R)own[0], (R)own[1], (R)own[2], acc);
-                mr = sor_finish_system<R, S>(acc, lr.dec());
-                // lines that another tile takes over later need the record in memory
-                if (active && (storeM || a >= WIN_BK - W + 1 || b >= WIN_BJ - W + 1)) {
-                    const long long e = win_index(tb, X, k, j, i);
-                    hk.wr(WIN_ARR_M, e, win);
-                    strec<S, 9>(A_.M + vM, e, mr);
-                }
-            } else {
-                mr = mx.dec();
-            }
-        } else {
-            mr = (sw ? SM : Hcur).dec();
         }
         R m[9];
 #pragma unroll
@@ -357,29 +357,15 @@ struct WinThread {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             lds.O[pc][q + 1][c][line] = out.v[c];
-            if (q == 0) lds.O[pc][0][c][line] = Lrec.v[c];
+            if constexpr (SLOT0) lds.O[pc][0][c][line] = Lrec.v[c];
             out_prev[c] = out.v[c];
             xp_prev[c] = xp[c];
         }
-        if (q + 1 < W) {
-            // the record travels on: slot q+1 reads it in the next step and uses it in the one after
-            RawRec<S, 9> raw;
-            if (q == 0) {
-                // re-encode: slot 0 holds decoded values
-                if constexpr (std::is_same<S, pk42>::value) {
-                    alignas(16) S tmp[12];
-                    strec<S, 9>(tmp, 0, mr);
-                    raw = *reinterpret_cast<const RawRec<S, 9> *>(tmp);
-                } else {
-#pragma unroll
-                    for (int n = 0; n < 9; n++) raw.w[n] = mr.v[n];
-                }
-            } else {
-                raw = sw ? SM : Hcur;
-            }
-            words_put(lds.H[pc][q], raw);
-        }
-        Hcur = Hnext;
+        // the record travels on: slot q+1 reads it at the end of the next step and uses it in the one after
+        if (q + 1 < W) words_put(lds.H[pc][q], SLOT0 ? encode9(mr) : Hcur);
+        // the system of the NEXT step's voxel, handed over by slot q-1 in step s-1 (the image of step s-1 is stable
+        // until the barrier)
+        if constexpr (!SLOT0) Hcur = words_get<RawRec<S, 9>>(lds.H[pp][q - 1]);
         if (active) {
             const bool fin = q == nsl - 1;
             const bool exp_ = q < W - 1 && (a == WIN_BK - 1 - q || b == WIN_BJ - 1 - q);
@@ -391,8 +377,14 @@ struct WinThread {
             }
         }
     }
+
+    FR3D_HD void step(const WinArgs<S> &wa, const Tab &tb, int s, Lds &lds, const Hook &hk)
+    {
+        if (q == 0) step_t<true>(wa, tb, s, lds, hk);
+        else step_t<false>(wa, tb, s, lds, hk);
+    }
 };
 
-#define WIN_LEAD 3  // steps the kernel runs ahead of the tile's first voxel (2 needed: loader, own-old pipeline)
+#define WIN_LEAD 4  // steps the kernel runs ahead of the tile's first voxel (2 needed: loader, own-old pipeline)
 
 }  // namespace fr3d

@@ -13,14 +13,13 @@ pytestmark = pytest.mark.gpu
 
 CASES = [
     # shape, channels, iterations, update_lag, levels, modes
-    # (fp64 storage, mode 2, takes the plane sweep whatever is asked for: its hand-off records do not fit the LDS)
-    ((24, 40, 36), 1, 20, 5, 2, (0, 1, 3)),        # several tiles in y, partly filled tiles
-    ((33, 35, 50), 1, 12, 5, 3, (1, 3)),           # last window shorter than the lag
-    ((40, 20, 33), 1, 14, 7, 2, (1, 3)),           # psi period longer than a window: the system is re-read
-    ((20, 48, 24), 1, 9, 3, 2, (1, 3)),            # psi period shorter than the window size
-    ((18, 34, 40), 1, 6, 1, 1, (3,)),              # a psi update on every iteration
-    ((36, 36, 20), 2, 10, 5, 2, (1, 3)),           # two channels
-    ((7, 9, 11), 1, 10, 5, 1, (1, 3)),             # one partly filled tile
+    ((24, 40, 36), 1, 20, 5, 2, (0, 1, 2, 3)),     # several tiles in y and z, partly filled tiles
+    ((33, 35, 50), 1, 12, 5, 3, (1, 2, 3)),        # last window shorter than the lag
+    ((40, 20, 33), 1, 14, 7, 2, (2, 3)),           # psi period longer than a window: the system is re-read
+    ((20, 48, 24), 1, 9, 3, 2, (1, 2)),            # psi period shorter than the window size
+    ((18, 34, 40), 1, 6, 1, 1, (2,)),              # a psi update on every iteration
+    ((36, 36, 20), 2, 10, 5, 2, (1, 3)),           # two channels (with fp64 storage they take the plane sweep: LDS)
+    ((7, 9, 11), 1, 10, 5, 1, (1, 2)),             # one partly filled tile
 ]
 
 
@@ -47,7 +46,7 @@ def test_window_sweep_in_a_lockstep_batch(hip):
     refp = ref_v[..., None].astype(np.float64)
     ex = HipExecutor3D()
     fp = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=15, levels=2, min_level=0, eta=0.8, a_smooth=1.0,
-              a_data=0.45, solver_fp64=3)
+              a_data=0.45, solver_fp64=2)
     outs = {}
     for sweep in ("planes", "window"):
         _, flows = ex.process_batch(batch, batch.astype(np.float64), refp, refp, np.zeros(shape + (3,), np.float32),
