@@ -75,6 +75,8 @@ SIGNATURES = {
     "fr3d_motion_tensor_f64": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _vp]),
     "fr3d_level_solve_verify": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,
                                           C.c_double, C.c_double, C.c_double, _vp]),
+    "fr3d_level_solve_tensor": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,
+                                          C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
     "fr3d_warp": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_warp_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_process_batch": (C.c_int, [C.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int,
@@ -89,6 +91,10 @@ SIGNATURES = {
                                   _vp, C.c_int]),
     "fr3d_preprocess_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
                                       C.c_double, _vp, C.c_int]),
+    "fr3d_gaussian_filter": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                       C.c_double, C.c_int, _vp, C.c_int]),
+    "fr3d_gaussian_filter_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp,
+                                           C.c_double, C.c_int, _vp, C.c_int]),
     "fr3d_update_reference": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, _dp]),
     "fr3d_update_reference_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

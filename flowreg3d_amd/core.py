@@ -252,13 +252,18 @@ def get_motion_tensor_gc(f1, f2, hz, hy, hx, return_factors=False):
     return (out, A) if return_factors else out
 
 
+class TensorRankError(ValueError):
+    """the motion tensor is not (numerically) of rank <= 3: no square-root factors"""
+
+
 def tensor_factors(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34):
     """Rank-3 square-root factors A (12, ...) with J = sum_k a_k a_k^T (k = 0..2, a_k in R^4) of the
     symmetric PSD 4x4 motion tensor given entry-wise (any leading shape), in float64.
 
     The reference's tensor is a sum of three outer products (core/optical_flow_3d.py:134-143), so
     the three leading eigenpairs reproduce it; psi_data's quadratic form d^T J d then becomes
-    sum_k (a_k . d)^2, which is how the device evaluates it."""
+    sum_k (a_k . d)^2, which is how the device evaluates it.  Raises TensorRankError for a tensor of higher
+    rank (level_solver then solves on the tensor entries instead)."""
     raw = [np.asarray(j) for j in (J11, J22, J33, J44, J12, J13, J23, J14, J24, J34)]
     Js = [j.astype(np.float64, copy=False) for j in raw]
     shp = Js[0].shape
@@ -274,12 +279,11 @@ def tensor_factors(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34):
         M[..., r, c] = Js[k]
         M[..., c, r] = Js[k]
     lam, V = np.linalg.eigh(M)          # ascending
-    # the device solver keeps three factors: a tensor that is not (numerically) rank <= 3 -- e.g. one built by
-    # another constancy assumption -- would silently be solved as a different system, so it is refused
+    # the factor solver keeps three factors: a tensor that is not (numerically) rank <= 3 -- e.g. one built by
+    # another constancy assumption -- would silently be solved as a different system
     trace = np.maximum(lam.sum(axis=-1), 0.0)
     if np.any(np.abs(lam[..., 0]) > rank_tol * trace + 1e-300):
-        raise ValueError(f"level_solver: the motion tensor is not rank 3 (smallest eigenvalue exceeds {rank_tol:.1e} of the "
-                         "trace); the device solver takes the gradient-constancy tensor of get_motion_tensor_gc")
+        raise TensorRankError(f"the motion tensor is not rank 3 (smallest eigenvalue exceeds {rank_tol:.1e} of the trace)")
     lam = np.clip(lam[..., 1:], 0.0, None)  # three leading eigenvalues
     V = V[..., :, 1:]
     A = np.sqrt(lam)[..., None, :] * V  # (..., 4, 3): column k = a_k
@@ -294,8 +298,11 @@ def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v,
     J*, weight: (P,M,N,C) with the zero outer ring; u,v,w: (P,M,N) edge-padded level flow.  Only the
     interior is solved (as in the reference); the returned ghost ring is the edge pad of the
     interior (the reference leaves the Neumann copy of the previous iterate there; it is never read
-    downstream, core/optical_flow_3d.py:517-535).  The tensor must be the rank-3 gradient-constancy
-    tensor get_motion_tensor_gc produces (see tensor_factors)."""
+    downstream, core/optical_flow_3d.py:517-535).
+
+    The rank-3 gradient-constancy tensor of get_motion_tensor_gc takes the production solver (square-root factors,
+    fr3d_level_solve).  ANY OTHER tensor -- the reference accepts whatever its caller built -- is solved on its
+    entries by fr3d_level_solve_tensor: the reference's own arithmetic in fp64 (the verification mode's sweep; slower)."""
     Js = [np.asarray(j) for j in (J11, J22, J33, J44, J12, J13, J23, J14, J24, J34)]
     if Js[0].ndim == 3:
         Js = [j[..., None] for j in Js]
@@ -309,16 +316,27 @@ def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v,
         if a.shape != (P, M, N):
             raise ValueError(f"{name} must have shape {(P, M, N)}")
         if not np.array_equal(a, np.pad(a[inner], 1, mode="edge")):
+            # every device kernel takes the ghost ring of u as the edge pad of its interior (add_boundary, :88); a
+            # caller-chosen ring would enter the surface voxels' stencil and psi_smooth
             raise NotImplementedError("u, v, w must be edge-padded (add_boundary) as in get_displacement")
     Ji = [np.moveaxis(j[inner], -1, 0) for j in Js]  # each (C,Z,Y,X)
-    Ad = _f32c(tensor_factors(*Ji))  # (12,C,Z,Y,X)
     wd = _f32c(np.moveaxis(wt[inner], -1, 0))
-    uvw = np.stack([np.asarray(a)[inner] for a in (u, v, w)], 0).astype(np.float32)
-    out = np.empty((3, P - 2, M - 2, N - 2), np.float32)
     al = (C.c_double * 3)(*[float(x) for x in alpha])
     ad_np = np.broadcast_to(np.asarray(a_data, dtype=np.float64).reshape(-1), (nc,))
     ad = (C.c_double * nc)(*[float(x) for x in ad_np])
     lib = _lib.init()
+    try:
+        Ad = _f32c(tensor_factors(*Ji))  # (12,C,Z,Y,X)
+    except TensorRankError:
+        Jin = np.ascontiguousarray(np.stack([np.stack([Ji[q][c] for q in range(10)]) for c in range(nc)]), np.float64)
+        uvw64 = np.ascontiguousarray(np.stack([np.asarray(a)[inner] for a in (u, v, w)], 0), np.float64)
+        out64 = np.empty((3, P - 2, M - 2, N - 2), np.float64)
+        _lib.check(lib.fr3d_level_solve_tensor(_lib.ptr(Jin), _lib.ptr(wd), _lib.ptr(uvw64), P - 2, M - 2, N - 2, nc, al,
+                                               int(iterations), int(update_lag), ad, float(a_smooth), float(hx), float(hy),
+                                               float(hz), _lib.ptr(out64)))
+        return tuple(np.pad(out64[d], 1, mode="edge") for d in range(3))
+    uvw = np.stack([np.asarray(a)[inner] for a in (u, v, w)], 0).astype(np.float32)
+    out = np.empty((3, P - 2, M - 2, N - 2), np.float32)
     _lib.check(lib.fr3d_level_solve(_lib.ptr(Ad), _lib.ptr(wd), _lib.ptr(uvw), P - 2, M - 2, N - 2,
                                     nc, al, int(iterations), int(update_lag), ad, float(a_smooth), float(hx),
                                     float(hy), float(hz), 1 if solver_fp64 else 0, _lib.ptr(out)))

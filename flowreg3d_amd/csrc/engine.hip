@@ -1496,9 +1496,10 @@ const double *Engine::gauss_kernel(double sigma, double truncate, int &radius)
 
 template <typename TIN>
 static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int X, int C, const double *nmin,
-                         const double *nden, const double *sigma, double truncate, void *out, int out_dtype)
+                         const double *nden, const double *sigma, double truncate, int mode, void *out, int out_dtype)
 {
     const long long n = (long long)T * Z * Y * X;
+    const bool fastk = mode == FR3D_BOUNDARY_REFLECT;  // the radius-4 kernels are written for the pipeline's mode
     double *bufA = e.f64("pp_a", (size_t)n);
     double *bufB = e.f64("pp_b", (size_t)n);
     Span sp(e, FR3D_K_PREPROC, 0, 0, 0);
@@ -1526,7 +1527,8 @@ static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int 
             const bool first = p == 0, last = p == np - 1;
             bool done = false;
             // fast kernels (radius 4): the last pass writes the caller's array itself
-            if (last) {
+            if (!fastk) {
+            } else if (last) {
                 if (out_dtype == FR3D_F64)
                     done = first ? launch_gauss_pass4<TIN, double, true>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, (double *)out, C, c)
                                  : launch_gauss_pass4<double, double, false>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, (double *)out, C, c);
@@ -1543,8 +1545,8 @@ static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int 
                 if (done) bytes += (double)n * ((first ? sizeof(TIN) : 8.0) + 8.0);
             }
             if (!done) {  // any other radius / a very short axis: the general kernel
-                if (first) launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, dst);
-                else launch_gauss_pass<double>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, dst);
+                if (first) launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, mode, dst);
+                else launch_gauss_pass<double>(e.st, cur, 1, 0, 0.0, 1.0, T, Z, Y, X, ps[p].axis, ps[p].w, ps[p].radius, mode, dst);
                 bytes += (double)n * ((first ? sizeof(TIN) : 8.0) + 8.0);
             }
             launches++;
@@ -1556,7 +1558,7 @@ static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int 
         if (np == 0) {  // no filtering at all: normalisation only (a radius-0 pass)
             int r0;
             const double *dw = e.gauss_kernel(0.0, truncate, r0);  // radius 0: the single tap 1.0
-            launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, 3, dw, 0, dst);
+            launch_gauss_pass<TIN>(e.st, frames, C, c, nmin[c], nden[c], T, Z, Y, X, 3, dw, 0, mode, dst);
             cur = dst;
             launches++;
             bytes += (double)n * (sizeof(TIN) + 8.0);
@@ -1574,8 +1576,10 @@ static void preprocess_t(Engine &e, const TIN *frames, int T, int Z, int Y, int 
 }
 
 static void preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *nmin,
-                           const double *nden, const double *sigma, double truncate, void *out, int out_dtype)
+                           const double *nden, const double *sigma, double truncate, void *out, int out_dtype,
+                           int mode = FR3D_BOUNDARY_REFLECT)
 {
+    FR3D_CHECK(mode >= FR3D_BOUNDARY_REFLECT && mode <= FR3D_BOUNDARY_WRAP, "unknown boundary mode");
     ensure_init();
     FR3D_CHECK(frames && nmin && nden && sigma && out, "NULL pointer");
     FR3D_CHECK(T >= 0 && Z >= 1 && Y >= 1 && X >= 1 && C >= 1 && C <= FR3D_MAX_CHANNELS, "bad preprocess shape");
@@ -1584,11 +1588,11 @@ static void preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, i
     for (int c = 0; c < C; c++) FR3D_CHECK(nden[c] != 0.0, "normalisation denominator is zero");
     Engine &e = g_eng;
     switch (dtype) {
-        case FR3D_F32: preprocess_t<float>(e, (const float *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
-        case FR3D_F64: preprocess_t<double>(e, (const double *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
-        case FR3D_U8: preprocess_t<unsigned char>(e, (const unsigned char *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
-        case FR3D_U16: preprocess_t<unsigned short>(e, (const unsigned short *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
-        case FR3D_I16: preprocess_t<short>(e, (const short *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, out, out_dtype); break;
+        case FR3D_F32: preprocess_t<float>(e, (const float *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, mode, out, out_dtype); break;
+        case FR3D_F64: preprocess_t<double>(e, (const double *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, mode, out, out_dtype); break;
+        case FR3D_U8: preprocess_t<unsigned char>(e, (const unsigned char *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, mode, out, out_dtype); break;
+        case FR3D_U16: preprocess_t<unsigned short>(e, (const unsigned short *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, mode, out, out_dtype); break;
+        case FR3D_I16: preprocess_t<short>(e, (const short *)frames, T, Z, Y, X, C, nmin, nden, sigma, truncate, mode, out, out_dtype); break;
         default: throw Error("unknown dtype code");
     }
     FR3D_HIP(hipStreamSynchronize(e.st));
@@ -1831,11 +1835,12 @@ int fr3d_motion_tensor_f64(const float *f1, const float *f2, int Z, int Y, int X
     FR3D_CATCH
 }
 
-int fr3d_level_solve_verify(const double *J, const float *weight, const float *uvw, int Z, int Y, int X, int C,
-                            const double *alpha3, int iterations, int update_lag, const double *a_data, double hx,
-                            double hy, double hz, double *duvw_out)
+// level_solver on tensor ENTRIES in the reference's own arithmetic (k_verify.hip): the sweep of the verification mode,
+// a_smooth == 1 or not; uvw fp32 or fp64
+static void level_solve_entries(const double *J, const float *weight, const void *uvw, bool uvw_f64, int Z, int Y, int X,
+                                int C, const double *alpha3, int iterations, int update_lag, const double *a_data,
+                                double a_smooth, double hx, double hy, double hz, double *duvw_out)
 {
-    FR3D_TRY
     ensure_init();
     FR3D_CHECK(J && weight && uvw && alpha3 && a_data && duvw_out, "NULL pointer");
     FR3D_CHECK(Z > 0 && Y > 0 && X > 0 && C >= 1 && C <= FR3D_MAX_CHANNELS, "bad solver shape");
@@ -1847,7 +1852,7 @@ int fr3d_level_solve_verify(const double *J, const float *weight, const float *u
     Staged s;
     const double *dJ = (const double *)s.up(J, n * 10 * C * 8);   // (C, 10, Z, Y, X)
     const float *dW = (const float *)s.up(weight, n * C * 4);      // (C, Z, Y, X)
-    const float *dU = (const float *)s.up(uvw, n * 3 * 4);         // (3, Z, Y, X)
+    const void *dU = s.up(uvw, n * 3 * (uvw_f64 ? 8 : 4));         // (3, Z, Y, X)
     double *Jrec = (double *)s.alloc(ns * 10 * C * 8);
     float *wrec = (float *)s.alloc(ns * C * 4);
     double *psi = (double *)s.alloc(ns * C * 8);
@@ -1867,17 +1872,51 @@ int fr3d_level_solve_verify(const double *J, const float *weight, const float *u
         a.psi[c] = psi + (size_t)c * ns;
         a.a_data[c] = a_data[c];
     }
-    launch_skew_pack<float, double>(e.st, dU, (long long)n, Urec, 3, sk);
+    if (uvw_f64) launch_skew_pack<double, double>(e.st, (const double *)dU, (long long)n, Urec, 3, sk);
+    else launch_skew_pack<float, double>(e.st, (const float *)dU, (long long)n, Urec, 3, sk);
     FR3D_HIP(hipMemsetAsync(Drec, 0, ns * 3 * 8, e.st));
     a.U = Urec;
     a.D = Drec;
     a.ax = alpha3[0] / (hx * hx);
     a.ay = alpha3[1] / (hy * hy);
     a.az = alpha3[2] / (hz * hz);
-    launch_sor_verify(e.st, a, e.chain_sched(sk, iterations));
+    if (a_smooth == 1.0) {
+        launch_sor_verify(e.st, a, e.chain_sched(sk, iterations));
+    } else {
+        // one iteration at a time, as in get_displacement_verify: psi_smooth of t from the increments of t-1 (interior)
+        // and t-2 (ghost ring), then one lexicographic sweep
+        double *Dm2 = (double *)s.alloc(ns * 3 * 8);
+        double *Ps = (double *)s.alloc((size_t)(Z + 2) * (Y + 2) * (X + 2) * 8);
+        FR3D_HIP(hipMemsetAsync(Dm2, 0, ns * 3 * 8, e.st));
+        a.Ps = Ps;
+        const SorChainSched &one = e.chain_sched(sk, 1);
+        for (int it = 0; it < iterations; it++) {
+            launch_psi_smooth_verify(e.st, sk, Urec, Drec, Dm2, a_smooth, hx, hy, hz, Ps);
+            FR3D_HIP(hipMemcpyAsync(Dm2, Drec, ns * 3 * 8, hipMemcpyDeviceToDevice, e.st));
+            a.t_base = it;
+            launch_sor_verify(e.st, a, one);
+        }
+    }
     launch_unskew_unpack<double, double>(e.st, Drec, dn, (long long)n, 3, sk);
     FR3D_HIP(hipStreamSynchronize(e.st));
     FR3D_HIP(hipMemcpy(duvw_out, dn, n * 3 * 8, hipMemcpyDeviceToHost));
+}
+
+int fr3d_level_solve_verify(const double *J, const float *weight, const float *uvw, int Z, int Y, int X, int C,
+                            const double *alpha3, int iterations, int update_lag, const double *a_data, double hx,
+                            double hy, double hz, double *duvw_out)
+{
+    FR3D_TRY
+    level_solve_entries(J, weight, uvw, false, Z, Y, X, C, alpha3, iterations, update_lag, a_data, 1.0, hx, hy, hz, duvw_out);
+    FR3D_CATCH
+}
+
+int fr3d_level_solve_tensor(const double *J, const float *weight, const double *uvw, int Z, int Y, int X, int C,
+                            const double *alpha3, int iterations, int update_lag, const double *a_data, double a_smooth,
+                            double hx, double hy, double hz, double *duvw_out)
+{
+    FR3D_TRY
+    level_solve_entries(J, weight, uvw, true, Z, Y, X, C, alpha3, iterations, update_lag, a_data, a_smooth, hx, hy, hz, duvw_out);
     FR3D_CATCH
 }
 
@@ -2152,16 +2191,18 @@ int fr3d_mean_stack_dev(const float *stack, int count, size_t n, float *out)
     FR3D_CATCH
 }
 
-int fr3d_preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *norm_min,
-                        const double *norm_den, const double *sigma, double truncate, void *out, int out_dtype)
+int fr3d_gaussian_filter_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *norm_min,
+                             const double *norm_den, const double *sigma, double truncate, int mode, void *out,
+                             int out_dtype)
 {
     FR3D_TRY
-    preprocess_dev(frames, dtype, T, Z, Y, X, C, norm_min, norm_den, sigma, truncate, out, out_dtype);
+    preprocess_dev(frames, dtype, T, Z, Y, X, C, norm_min, norm_den, sigma, truncate, out, out_dtype, mode);
     FR3D_CATCH
 }
 
-int fr3d_preprocess(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *norm_min,
-                    const double *norm_den, const double *sigma, double truncate, void *out, int out_dtype)
+int fr3d_gaussian_filter(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *norm_min,
+                         const double *norm_den, const double *sigma, double truncate, int mode, void *out,
+                         int out_dtype)
 {
     FR3D_TRY
     ensure_init();
@@ -2172,9 +2213,23 @@ int fr3d_preprocess(const void *frames, int dtype, int T, int Z, int Y, int X, i
     Staged s;
     const void *din = s.up(frames, n * dtype_size(dtype));
     void *dout = s.alloc(n * dtype_size(out_dtype));
-    preprocess_dev(din, dtype, T, Z, Y, X, C, norm_min, norm_den, sigma, truncate, dout, out_dtype);
+    preprocess_dev(din, dtype, T, Z, Y, X, C, norm_min, norm_den, sigma, truncate, dout, out_dtype, mode);
     FR3D_HIP(hipMemcpy(out, dout, n * dtype_size(out_dtype), hipMemcpyDeviceToHost));
     FR3D_CATCH
+}
+
+int fr3d_preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *norm_min,
+                        const double *norm_den, const double *sigma, double truncate, void *out, int out_dtype)
+{
+    return fr3d_gaussian_filter_dev(frames, dtype, T, Z, Y, X, C, norm_min, norm_den, sigma, truncate,
+                                    FR3D_BOUNDARY_REFLECT, out, out_dtype);
+}
+
+int fr3d_preprocess(const void *frames, int dtype, int T, int Z, int Y, int X, int C, const double *norm_min,
+                    const double *norm_den, const double *sigma, double truncate, void *out, int out_dtype)
+{
+    return fr3d_gaussian_filter(frames, dtype, T, Z, Y, X, C, norm_min, norm_den, sigma, truncate, FR3D_BOUNDARY_REFLECT,
+                                out, out_dtype);
 }
 
 static void flow_stats_dev(const float *flows, int T, int Z, int Y, int X, double *out)

@@ -413,7 +413,7 @@ void launch_accum_round_once(hipStream_t st, float *u, const double *d, long lon
 // f-1 preprocessing (k_preproc.hip)
 template <typename TIN>
 void launch_gauss_pass(hipStream_t st, const TIN *in, int cs, int co, double nmin, double nden, int T, int Z,
-                       int Y, int X, int axis, const double *w, int radius, double *out);
+                       int Y, int X, int axis, const double *w, int radius, int mode, double *out);
 template <typename TOUT>
 void launch_store_channel(hipStream_t st, const double *in, long long n, int C, int c, TOUT *out);
 // radius-4 pass (sigma 1): normalise once per loaded element (NORM), register window / LDS segment, output element e at

@@ -19,12 +19,38 @@ __device__ __forceinline__ int reflect_hs(int i, int n)
     if (i < 0) i += period;
     return i < n ? i : period - 1 - i;
 }
+// scipy.ndimage boundary modes (NI_ExtendLine) as an index map; -1 = outside (mode "constant", cval 0)
+//   FR3D_BOUNDARY_REFLECT  d c b a | a b c d | d c b a      (also "grid-mirror")
+//   FR3D_BOUNDARY_CONSTANT 0 0 0 0 | a b c d | 0 0 0 0      (also "grid-constant")
+//   FR3D_BOUNDARY_NEAREST  a a a a | a b c d | d d d d
+//   FR3D_BOUNDARY_MIRROR   d c b | a b c d | c b a
+//   FR3D_BOUNDARY_WRAP     a b c d | a b c d | a b c d      (also "grid-wrap")
+__device__ __forceinline__ int extend_index(int i, int n, int mode)
+{
+    if (i >= 0 && i < n) return i;
+    switch (mode) {
+        case FR3D_BOUNDARY_CONSTANT: return -1;
+        case FR3D_BOUNDARY_NEAREST: return i < 0 ? 0 : n - 1;
+        case FR3D_BOUNDARY_MIRROR: {
+            if (n == 1) return 0;
+            const int period = 2 * n - 2;
+            i %= period;
+            if (i < 0) i += period;
+            return i < n ? i : period - i;
+        }
+        case FR3D_BOUNDARY_WRAP: {
+            i %= n;
+            return i < 0 ? i + n : i;
+        }
+        default: return reflect_hs(i, n);
+    }
+}
 
 // in: element (t,z,y,x) at ((t*Z+z)*Y+y)*X+x) * cs + co ; out planar fp64
 template <typename TIN>
 __global__ void __launch_bounds__(256)
 k_gauss_pass(const TIN *__restrict__ in, int cs, int co, double nmin, double nden, int T, int Z, int Y, int X,
-             int axis, const double *__restrict__ w, int radius, double *__restrict__ out)
+             int axis, const double *__restrict__ w, int radius, int mode, double *__restrict__ out)
 {
     const long long total = (long long)T * Z * Y * X;
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,7 +61,11 @@ k_gauss_pass(const TIN *__restrict__ in, int cs, int co, double nmin, double nde
     const long long st = strides[axis];
     const int l = (int)((e / st) % n);
     const long long base = e - (long long)l * st;
-    auto at = [&](int i) -> double { return ((double)in[(size_t)(base + (long long)i * st) * cs + co] - nmin) / nden; };
+    // (outside, mode "constant": the filter pads the NORMALISED array with cval = 0)
+    auto at = [&](int i) -> double {
+        const double x = ((double)in[(size_t)(base + (long long)(i < 0 ? 0 : i) * st) * cs + co] - nmin) / nden;
+        return i < 0 ? 0.0 : x;
+    };
     const double *fw = w + radius;
     double tmp = at(l) * fw[0];
     // four tap pairs per trip: their eight loads are independent and leave together; the sum keeps
@@ -45,8 +75,8 @@ k_gauss_pass(const TIN *__restrict__ in, int cs, int co, double nmin, double nde
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int jj = j0 + q < 0 ? j0 + q : -1;  // clamped: always a valid tap, discarded below
-            lo[q] = at(reflect_hs(l + jj, n));
-            hi[q] = at(reflect_hs(l - jj, n));
+            lo[q] = at(extend_index(l + jj, n, mode));
+            hi[q] = at(extend_index(l - jj, n, mode));
         }
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -57,19 +87,19 @@ k_gauss_pass(const TIN *__restrict__ in, int cs, int co, double nmin, double nde
 
 template <typename TIN>
 void launch_gauss_pass(hipStream_t st, const TIN *in, int cs, int co, double nmin, double nden, int T, int Z,
-                       int Y, int X, int axis, const double *w, int radius, double *out)
+                       int Y, int X, int axis, const double *w, int radius, int mode, double *out)
 {
     const long long total = (long long)T * Z * Y * X;
     if (total == 0) return;
     hipLaunchKernelGGL(k_gauss_pass<TIN>, dim3(cdiv(total, 256)), dim3(256), 0, st, in, cs, co, nmin, nden, T, Z, Y,
-                       X, axis, w, radius, out);
+                       X, axis, w, radius, mode, out);
     FR3D_LAUNCH_CHECK();
 }
-template void launch_gauss_pass<float>(hipStream_t, const float *, int, int, double, double, int, int, int, int, int, const double *, int, double *);
-template void launch_gauss_pass<double>(hipStream_t, const double *, int, int, double, double, int, int, int, int, int, const double *, int, double *);
-template void launch_gauss_pass<unsigned char>(hipStream_t, const unsigned char *, int, int, double, double, int, int, int, int, int, const double *, int, double *);
-template void launch_gauss_pass<unsigned short>(hipStream_t, const unsigned short *, int, int, double, double, int, int, int, int, int, const double *, int, double *);
-template void launch_gauss_pass<short>(hipStream_t, const short *, int, int, double, double, int, int, int, int, int, const double *, int, double *);
+template void launch_gauss_pass<float>(hipStream_t, const float *, int, int, double, double, int, int, int, int, int, const double *, int, int, double *);
+template void launch_gauss_pass<double>(hipStream_t, const double *, int, int, double, double, int, int, int, int, int, const double *, int, int, double *);
+template void launch_gauss_pass<unsigned char>(hipStream_t, const unsigned char *, int, int, double, double, int, int, int, int, int, const double *, int, int, double *);
+template void launch_gauss_pass<unsigned short>(hipStream_t, const unsigned short *, int, int, double, double, int, int, int, int, int, const double *, int, int, double *);
+template void launch_gauss_pass<short>(hipStream_t, const short *, int, int, double, double, int, int, int, int, int, const double *, int, int, double *);
 
 // ---- the fast passes (round 4): radius 4 = sigma 1, the OFOptions default (OF_options_3D.py:171) ----------------------
 // Same arithmetic, same order of the sum as k_gauss_pass (results are bit-identical); what changes is the work per

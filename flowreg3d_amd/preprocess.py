@@ -48,7 +48,12 @@ def _sigma_table(sigma, nc):
     return tab
 
 
-def _run(arr, mins, dens, sigma, truncate, spatial_only, out_dtype):
+# scipy.ndimage boundary modes -> FR3D_BOUNDARY_* (include/flowreg3d_hip.h)
+_MODES = {"reflect": 0, "grid-mirror": 0, "constant": 1, "grid-constant": 1, "nearest": 2, "mirror": 3, "wrap": 4,
+          "grid-wrap": 4}
+
+
+def _run(arr, mins, dens, sigma, truncate, spatial_only, out_dtype, mode="reflect"):
     a = np.asarray(arr)
     squeeze_t = a.ndim == 4
     if a.ndim not in (4, 5):
@@ -67,9 +72,11 @@ def _run(arr, mins, dens, sigma, truncate, spatial_only, out_dtype):
     dp = C.POINTER(C.c_double)
     mins = np.ascontiguousarray(mins, dtype=np.float64)
     dens = np.ascontiguousarray(dens, dtype=np.float64)
-    _lib.check(lib.fr3d_preprocess(_lib.ptr(a), _DTYPES[a.dtype], T, Z, Y, X, nc, mins.ctypes.data_as(dp),
-                                   dens.ctypes.data_as(dp), tab.ctypes.data_as(dp), float(truncate), _lib.ptr(out),
-                                   out_dtype))
+    if mode not in _MODES:
+        raise RuntimeError(f"boundary mode not supported: {mode!r}")  # scipy raises RuntimeError for an unknown mode
+    _lib.check(lib.fr3d_gaussian_filter(_lib.ptr(a), _DTYPES[a.dtype], T, Z, Y, X, nc, mins.ctypes.data_as(dp),
+                                        dens.ctypes.data_as(dp), tab.ctypes.data_as(dp), float(truncate), _MODES[mode],
+                                        _lib.ptr(out), out_dtype))
     return out[0] if squeeze_t else out
 
 
@@ -89,11 +96,10 @@ def normalize(arr, ref=None, channel_normalization="together", eps=1e-8):
 
 
 def apply_gaussian_filter(arr, sigma, mode="reflect", truncate=4.0):
-    """util/image_processing_3D.py:95-162 on the device -> float64."""
-    if mode != "reflect":
-        raise NotImplementedError("only mode='reflect' (what the pipeline passes)")
+    """util/image_processing_3D.py:95-162 on the device -> float64; ``mode`` is any of scipy.ndimage's boundary modes
+    (constant: cval = 0, as scipy.ndimage.gaussian_filter's default)."""
     nc = np.asarray(arr).shape[-1]
-    return _run(arr, np.zeros(nc), np.ones(nc), sigma, truncate, False, _lib.F64)
+    return _run(arr, np.zeros(nc), np.ones(nc), sigma, truncate, False, _lib.F64, mode)
 
 
 def preprocess_frames(frames, normalization_ref=None, sigma=((1, 1, 1, 0.1), (1, 1, 1, 0.1)),

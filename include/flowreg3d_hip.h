@@ -60,12 +60,14 @@ typedef struct fr3d_params {
                                              to 2^22 voxels, 3 above; several channels: 2 (what the Python mirror
                                              passes by default) */
     int solver_sweep;                  /* which kernel runs the a_smooth == 1 sweep (results are bit-identical):
-                                          FR3D_SWEEP_AUTO (0): the engine's choice per level;
+                                          FR3D_SWEEP_AUTO (0): the engine's choice (PLANES: it measured faster in
+                                             every storage format; env FR3D_SWEEP overrides);
                                           FR3D_SWEEP_PLANES (1): one launch per hyperplane step, every iteration's
                                              operands streamed from HBM (k_sor.hip);
-                                          FR3D_SWEEP_WINDOW (2): a whole psi window (update_lag iterations) per
-                                             workgroup on chip, tiles of lines marching along x (k_sor_win.hip;
-                                             1 or 2 channels, PLANES otherwise) */
+                                          FR3D_SWEEP_WINDOW (2): up to 5 iterations of a psi period per workgroup
+                                             on chip, tiles of lines marching along x (k_sor_win.hip; 1 or 2
+                                             channels -- 1 with fp64 storage --, PLANES otherwise; 12 more solver
+                                             values per voxel of workspace) */
     int reserved[6];
 } fr3d_params;
 #define FR3D_SOLVER_AUTO (-1)
@@ -100,7 +102,8 @@ int fr3d_set_batch(int nvol);
  * (batches of half the size: the same memory in total), lane 1 fed by a host thread of its own -- so that the stages of
  * one batch that do not fill the memory system (median, warps, motion tensor, the short launches of the coarse levels,
  * the ramp and tail of every sweep launch) run under the other batch's sweep: +9..12 % at 256^3.  Results are
- * bit-identical to one lane.  The progress callback is serialised but may come from either host thread.  The
+ * bit-identical to one lane.  The progress callback always runs on the CALLER's thread (lane 1 queues its events, the
+ * calling thread delivers them): a callback may re-enter the library and may be thread-affine, as with the reference.  The
  * reference's counterpart is its executor's worker pool (parallelization/multiprocessing_3d.py:286-318: several
  * batches in flight).  While profiling brackets are on (fr3d_prof_enable(1)) a call runs on ONE lane: the event spans
  * of two lanes overlap and would not be kernel times. */
@@ -146,6 +149,17 @@ int fr3d_level_solve_verify(const double *J, const float *weight, const float *u
                             const double *alpha3, int iterations, int update_lag, const double *a_data, double hx,
                             double hy, double hz, double *duvw_out);
 
+/* level_solver for ANY motion tensor (core/optical_flow_3d.py:262-316 takes whatever its caller built): the sweep in
+ * the reference's own arithmetic on tensor entries -- fp64, the expanded quadratic form of psi_data, psi_smooth
+ * re-evaluated every iteration when a_smooth != 1 (core/level_solver_3d.py:262-311,340-546) -- where
+ * fr3d_level_solve needs the rank-3 square-root factors of the gradient-constancy tensor.  Slower (no frozen system,
+ * one sweep per launch chain when a_smooth != 1); the Python mirror's level_solver takes it for tensors that are
+ * not rank 3.  J: (C,10,Z,Y,X) float64, order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 (interior); weight (C,Z,Y,X)
+ * fp32; uvw (3,Z,Y,X) float64 interior flow (ghosts = edge pad); duvw_out (3,Z,Y,X) float64. */
+int fr3d_level_solve_tensor(const double *J, const float *weight, const double *uvw, int Z, int Y, int X, int C,
+                            const double *alpha3, int iterations, int update_lag, const double *a_data,
+                            double a_smooth, double hx, double hy, double hz, double *duvw_out);
+
 /* Test hook: the verification mode's portable pow (flowreg3d_amd/csrc/portable_pow.h) evaluated on the device for n
  * host values -- tests compare it bit for bit with the same source compiled for the host. */
 int fr3d_portable_pow(const double *x, const double *y, size_t n, double *out);
@@ -165,7 +179,7 @@ int fr3d_warp_dev(const void *vol, int vol_dtype, const void *flow, int flow_dty
  * batch_proc/batch_raw: (T,Z,Y,X,C) fp32; ref_proc/ref_raw: (Z,Y,X,C) fp32;
  * flows_out: (T,Z,Y,X,3) fp32; registered_out: (T,Z,Y,X,C) fp32.
  * The fixed-reference pyramid is built once per call.  `progress` (nullable) is called with 1
- * after each volume (base_3d.py:46 progress_callback). */
+ * after each volume (base_3d.py:46 progress_callback), on the calling thread, also when two engine lanes run. */
 typedef void (*fr3d_progress_fn)(int volumes_done, void *user);
 int fr3d_process_batch(const fr3d_params *p, const float *batch_proc, const float *batch_raw,
                        const float *ref_proc, const float *ref_raw, const float *w_init,
@@ -210,6 +224,28 @@ int fr3d_preprocess(const void *frames, int dtype, int T, int Z, int Y, int X, i
 int fr3d_preprocess_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C,
                         const double *norm_min, const double *norm_den, const double *sigma,
                         double truncate, void *out, int out_dtype);
+
+/* The same passes with any of scipy.ndimage's boundary modes (util/image_processing_3D.py:95-162 hands `mode` through to
+ * scipy.ndimage.gaussian_filter; the pipeline itself only uses "reflect"): what lies beyond an edge of a b c d is
+ *   FR3D_BOUNDARY_REFLECT  d c b a | a b c d | d c b a   ("reflect", "grid-mirror")
+ *   FR3D_BOUNDARY_CONSTANT 0 0 0 0 | a b c d | 0 0 0 0   ("constant" / "grid-constant" with cval = 0, of the
+ *                                                          normalised array)
+ *   FR3D_BOUNDARY_NEAREST  a a a a | a b c d | d d d d   ("nearest")
+ *   FR3D_BOUNDARY_MIRROR   d c b   | a b c d | c b a     ("mirror")
+ *   FR3D_BOUNDARY_WRAP     a b c d | a b c d | a b c d   ("wrap", "grid-wrap")
+ * fr3d_preprocess* is this entry with FR3D_BOUNDARY_REFLECT (the specialised kernels; the other modes take the
+ * general pass). */
+#define FR3D_BOUNDARY_REFLECT 0
+#define FR3D_BOUNDARY_CONSTANT 1
+#define FR3D_BOUNDARY_NEAREST 2
+#define FR3D_BOUNDARY_MIRROR 3
+#define FR3D_BOUNDARY_WRAP 4
+int fr3d_gaussian_filter(const void *frames, int dtype, int T, int Z, int Y, int X, int C,
+                         const double *norm_min, const double *norm_den, const double *sigma,
+                         double truncate, int mode, void *out, int out_dtype);
+int fr3d_gaussian_filter_dev(const void *frames, int dtype, int T, int Z, int Y, int X, int C,
+                             const double *norm_min, const double *norm_den, const double *sigma,
+                             double truncate, int mode, void *out, int out_dtype);
 
 /* Reference update of the batch driver (BatchMotionCorrector._update_reference,
  * motion_correction/compensate_recording_3D.py:395-429): per channel, the last min(100,T) volumes of

@@ -306,11 +306,46 @@ def test_level_solver_accepts_the_engines_own_fp32_grade_tensor(hip):
     z = np.zeros((P, M, N))
     du, dv, dw = hip.level_solver(*J, wt, z, z, z, (0.25, 0.25, 0.25), 10, 5, False, 0.45, 1.0, 1.0, 1.0, 1.0)
     assert du.shape == (P, M, N) and np.isfinite(du).all() and np.abs(du).max() > 0
-    # a tensor that is genuinely not rank 3 is still refused
-    bad = [j.copy() for j in J]
-    bad[0] = bad[0] + 0.1 * (np.abs(bad[0]).max() + 1.0)
-    with pytest.raises(ValueError):
-        hip.level_solver(*bad, wt, z, z, z, (0.25, 0.25, 0.25), 3, 5, False, 0.45, 1.0, 1.0, 1.0, 1.0)
+
+
+@pytest.mark.parametrize("channels,a_smooth,lag", [(1, 1.0, 5), (2, 1.0, 2), (1, 0.5, 3), (2, 0.7, 1)])
+def test_level_solver_takes_any_tensor_like_the_reference(hip, oracle, channels, a_smooth, lag):
+    """VERDICT r3 (boundary restrictions): the reference's level_solver (core/optical_flow_3d.py:262-316) solves whatever
+    tensor it is handed.  A tensor that is NOT the rank-3 gradient-constancy tensor has no square-root factors; the
+    mirror then solves on the entries in the reference's arithmetic (fr3d_level_solve_tensor): bit-identical to the
+    oracle built with the same portable pow, for a_smooth == 1 and != 1, fp64 flow that is not fp32-representable."""
+    from flowreg3d_amd.synthetic import make_pair
+    from flowreg3d_amd.core import tensor_factors, TensorRankError
+    shape = (14, 22, 19)
+    fixed, moving, gt = make_pair(shape, seed=6, channels=channels, cheap=True)
+    if channels == 1:
+        fixed, moving = fixed[..., None], moving[..., None]
+    Js = [oracle.get_motion_tensor_gc(fixed[..., c], moving[..., c], 1.0, 1.2, 0.9) for c in range(channels)]
+    J = [np.stack([Js[c][q] for c in range(channels)], -1) for q in range(10)]
+    rng = np.random.default_rng(5)
+    # a brightness-constancy-like rank-1 term on top: rank 4, still symmetric PSD
+    g = rng.standard_normal((4,) + J[0].shape) * 0.3
+    g[:, 0], g[:, -1], g[:, :, 0], g[:, :, -1], g[:, :, :, 0], g[:, :, :, -1] = 0, 0, 0, 0, 0, 0
+    pairs = [(0, 0), (1, 1), (2, 2), (3, 3), (0, 1), (0, 2), (1, 2), (0, 3), (1, 3), (2, 3)]
+    J = [J[q] + g[r] * g[c] for q, (r, c) in enumerate(pairs)]
+    with pytest.raises(TensorRankError):
+        tensor_factors(*[np.moveaxis(j[1:-1, 1:-1, 1:-1], -1, 0) for j in J])
+    P, M, N = J[0].shape[:3]
+    wt = np.zeros((P, M, N, channels))
+    wt[1:-1, 1:-1, 1:-1] = rng.uniform(0.3, 1.0, (P - 2, M - 2, N - 2, channels)).astype(np.float32)
+    uvw = [np.pad(0.7 * gt[..., d] + 0.01 * rng.standard_normal(shape), 1, mode="edge") for d in range(3)]  # float64
+    a_data = [0.45, 0.6][:channels]
+    alpha = (0.3, 0.25, 0.2)
+    got = hip.level_solver(*J, wt, *uvw, alpha, 11, lag, False, a_data, a_smooth, 1.0, 1.2, 0.9)
+    try:
+        oracle.use_build("ppow")
+        want = oracle.compute_flow_3d(*J, wt, *uvw, *alpha, 11, lag, a_data, a_smooth, 1.0, 1.2, 0.9)
+    finally:
+        oracle.use_build("")
+    inner = (slice(1, -1),) * 3
+    for d in range(3):
+        assert got[d].dtype == np.float64 and got[d].shape == (P, M, N)
+        assert np.array_equal(got[d][inner], want[inner + (d,)]), (d, np.abs(got[d][inner] - want[inner + (d,)]).max())
 
 
 def test_workgroups_with_equal_id_mod_8_share_an_xcd(hip):

@@ -63,5 +63,30 @@ def test_gpu_preprocess_uint16_and_filter_only(hip, oracle):
     got = preprocess.apply_gaussian_filter(a, np.array([2.5, 0.0, 1.0]))  # sy = 0: axis skipped
     want = oracle.apply_gaussian_filter(a, np.array([2.5, 0.0, 1.0]))
     assert np.abs(got - want).max() < TOL
-    with pytest.raises(NotImplementedError):
-        preprocess.apply_gaussian_filter(a, np.ones(3), mode="nearest")
+    with pytest.raises(RuntimeError):  # scipy raises RuntimeError("boundary mode not supported") too
+        preprocess.apply_gaussian_filter(a, np.ones(3), mode="no-such-mode")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["reflect", "constant", "nearest", "mirror", "wrap", "grid-mirror", "grid-constant",
+                                  "grid-wrap"])
+def test_gpu_gaussian_filter_boundary_modes_match_scipy(hip, mode):
+    """apply_gaussian_filter hands `mode` to scipy.ndimage.gaussian_filter (util/image_processing_3D.py:95-162): every
+    boundary mode of scipy, against scipy itself -- volumes with axes shorter than the kernel radius (several
+    reflections / wraps), a 5-D batch with a temporal sigma, per-channel sigmas"""
+    from scipy.ndimage import gaussian_filter
+    from flowreg3d_amd import preprocess
+    rng = np.random.default_rng(7)
+    for shape, sigma in (((9, 12, 31, 2), np.array([1.0, 1.5, 0.8])),
+                         ((3, 2, 40, 1), np.array([2.0, 2.0, 2.0])),          # axes of 2 and 3 under radius 8
+                         ((1, 17, 6, 1), np.array([1.0, 1.0, 1.0])),          # an axis of length 1
+                         ((4, 6, 7, 9, 2), np.array([[1.0, 0.7, 1.2, 0.9], [0.5, 1.0, 1.0, 0.0]]))):
+        a = rng.random(shape)
+        got = preprocess.apply_gaussian_filter(a, sigma, mode=mode)
+        want = np.empty_like(a)
+        for c in range(shape[-1]):
+            s = sigma[min(c, len(sigma) - 1)] if sigma.ndim == 2 else sigma
+            s = tuple(s[::-1]) if a.ndim == 5 else (s[2], s[1], s[0])
+            want[..., c] = gaussian_filter(a[..., c], sigma=s, mode=mode, truncate=4.0)
+        assert got.dtype == np.float64
+        assert np.abs(got - want).max() < 4e-15, (mode, shape, np.abs(got - want).max())
