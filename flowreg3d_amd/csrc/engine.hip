@@ -1028,11 +1028,19 @@ static bool g_fast_path = true;  // a_smooth == 1 of the call in progress (the p
 static double g_storage_bytes = 4.0;  // bytes per stored solver value of the call in progress
 static bool g_window = false;         // the call in progress runs the window sweep (its export arrays count in the budget)
 
-// fr3d_set_batch(), else FR3D_BATCH, else 8
-static int batch_wanted()
+// Volumes solved in lock step: fr3d_set_batch(), else FR3D_BATCH, else 8 volumes of up to 2^24 voxels -- and the same
+// number of VOXELS for smaller volumes (up to 128 of them): a level of a small volume is a few thousand launches of
+// a few microseconds each whatever the batch, so a batch of 8 leaves the device idle (48^3: 384 volumes/s with 8 in lock
+// step, 707 with 128; 100^3: 138 -> 181; 64 x 256 x 256: 51 -> 58; profiles/r04/shape_rates.md).  Same workspace by
+// construction.
+static int batch_wanted(long long nvox)
 {
     static const char *env = getenv("FR3D_BATCH");
-    return g_batch_hint > 0 ? g_batch_hint : (env ? std::max(1, atoi(env)) : 8);
+    if (g_batch_hint > 0) return g_batch_hint;
+    if (env) return std::max(1, atoi(env));
+    long long f = nvox > 0 ? (1LL << 24) / nvox : 1;
+    f = std::max(1LL, std::min(16LL, f));
+    return (int)(8 * f);
 }
 
 // Bytes one volume of a lock-step batch holds on the finest level with `bytes` per stored solver value, and the HBM
@@ -1098,7 +1106,7 @@ static int resolve_mode(const fr3d_params &p, int C, int Z, int Y, int X, const 
 
 static int pick_batch(int T, const std::vector<Level> &lv, int C, int lanes = 1)
 {
-    int want = batch_wanted();
+    int want = batch_wanted((long long)lv.back().z * lv.back().y * lv.back().x);
     if (want > T) want = T;
     if (want < 1) want = 1;
     const double per_vol = solver_bytes_per_volume(lv, C, g_storage_bytes, g_fast_path, g_window);
@@ -2022,7 +2030,7 @@ int fr3d_process_batch_raw(const fr3d_params *p, const float *batch_proc, const 
     // stream computes window k+1, so the PCIe traffic (and the page faults of freshly allocated
     // host output arrays) hide behind the solver.  T is bounded by host memory only.
     const size_t per_vol = nv * ((size_t)C * (4 + 2 * rsz) + 12);
-    const int lock = batch_wanted();
+    const int lock = batch_wanted((long long)nv);
     const char *cap_env = getenv("FR3D_STAGE_KIB");  // staging budget override (tests use it to force windows)
     const size_t cap = cap_env ? (size_t)std::max(1, atoi(cap_env)) << 10 : (8ull << 30);
     int win = (int)std::max<size_t>(1, std::min<size_t>((size_t)lock, cap / per_vol));
