@@ -12,12 +12,15 @@ static double rf(double v, int on) { return on ? (double)(float)v : v; }
 
 /* flags: bit0 J stored fp32; bit1 d stored fp32; bit2 fp32 arithmetic; bit3 psi from factors A (12
  * arrays, stored fp32 if bit0); bit4 L stored fp32; bit5 wpsi stored fp32; bit6: sweep J from factors */
-void sor_probe(const double *const J[10], const double *const A[12], const double *weight,
-               const double *const Lin[3], int Z, int Y, int X, double ax, double ay, double az,
-               int iters, int lag, double adc, int flags, double *const dout[3])
+/* switch_it: from this iteration on the storage roundings are off (operands re-derived in full precision, increments
+ * and w psi stored in fp64): "the last iterations of a level in a wider format" (round 4 what-if).  >= iters: never. */
+void sor_probe_sw(const double *const J[10], const double *const A[12], const double *weight,
+                  const double *const Lin[3], int Z, int Y, int X, double ax, double ay, double az,
+                  int iters, int lag, double adc, int flags, int switch_it, double *const dout[3])
 {
-    const int J32 = flags & 1, D32 = (flags >> 1) & 1, AR32 = (flags >> 2) & 1, PF = (flags >> 3) & 1,
-              L32 = (flags >> 4) & 1, W32 = (flags >> 5) & 1, JF = (flags >> 6) & 1;
+    const int J32 = flags & 1, AR32 = (flags >> 2) & 1, PF = (flags >> 3) & 1,
+              L32 = (flags >> 4) & 1, JF = (flags >> 6) & 1;
+    int D32 = (flags >> 1) & 1, W32 = (flags >> 5) & 1;
     size_t n = (size_t)Z * Y * X;
     double *du = calloc(n, 8), *dv = calloc(n, 8), *dw = calloc(n, 8), *wpsi = malloc(n * 8);
     double *Jr[10], *Ar[12], *L[3];
@@ -35,6 +38,13 @@ void sor_probe(const double *const J[10], const double *const A[12], const doubl
     const double OM = 1.95;
     for (int it = 0; it < iters; it++) {
         int upd = (it % lag) == 0;
+        if (it == switch_it) {  /* wider storage from here on */
+            D32 = W32 = 0;
+            for (int a = 0; a < 10; a++) memcpy(Jr[a], J[a], n * 8);
+            for (int a = 0; a < 12; a++) memcpy(Ar[a], A[a], n * 8);
+            for (int a = 0; a < 3; a++) memcpy(L[a], Lin[a], n * 8);
+            if (!upd) for (size_t q = 0; q < n; q++) wpsi[q] = wpsi[q];  /* the frozen weights stay as stored */
+        }
         for (int k = 0; k < Z; k++) for (int j = 0; j < Y; j++) for (int i = 0; i < X; i++) {
             size_t c = I3(k, j, i);
             double u0 = du[c], v0 = dv[c], w0 = dw[c];
@@ -101,6 +111,13 @@ void sor_probe(const double *const J[10], const double *const A[12], const doubl
     for (int a = 0; a < 12; a++) free(Ar[a]);
     for (int a = 0; a < 3; a++) free(L[a]);
     free(du); free(dv); free(dw); free(wpsi);
+}
+
+void sor_probe(const double *const J[10], const double *const A[12], const double *weight,
+               const double *const Lin[3], int Z, int Y, int X, double ax, double ay, double az,
+               int iters, int lag, double adc, int flags, double *const dout[3])
+{
+    sor_probe_sw(J, A, weight, Lin, Z, Y, X, ax, ay, az, iters, lag, adc, flags, iters + 1, dout);
 }
 
 /* ---- defect-correction ("delta") form of the same sweep (round 4) -------------------------------------------
