@@ -36,6 +36,25 @@ def test_random_shapes_and_parameters_in_packed_storage(hip, oracle):
     assert bad == 0 and worst < 2e-4, (bad, worst)
 
 
+@pytest.mark.parametrize("mode", [2, 3])
+def test_random_shapes_and_parameters_through_the_window_sweep(hip, oracle, mode):
+    """the same generator with fr3d_params.solver_sweep = FR3D_SWEEP_WINDOW: one- and two-channel cases with a_smooth = 1
+    run the window kernel (k_sor_win.hip), everything else falls back to the plane sweep -- against the CPU oracle"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_vs_oracle
+    bad, worst = fuzz_vs_oracle.run(n_cases=30, seed=59 + mode, verbose=False, mode=mode, sweep=2)
+    assert bad == 0 and worst < (1e-4 if mode == 2 else 2e-4), (bad, worst)
+
+
+def test_verification_mode_with_psi_smooth_is_bit_identical_on_random_cases(hip, oracle):
+    """the verification mode on the random generator WITH a_smooth drawn from {1, 1, 0.5} (round 4: the psi_smooth
+    branch is covered): np.array_equal against the ppow oracle on every case"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_vs_oracle
+    bad, worst = fuzz_vs_oracle.run(n_cases=24, seed=71, verbose=False, mode="verify", verify_smooth=True)
+    assert bad == 0, (bad, worst)
+
+
 def test_verification_mode_is_bit_identical_on_random_shapes_and_parameters(hip, oracle):
     """the verification mode against the oracle's ppow build on the random generator (axes of length 1..70, 1..6
     channels, random pyramid / solver parameters, initial flows, weights): np.array_equal on every case, and the

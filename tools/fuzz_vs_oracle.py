@@ -14,10 +14,12 @@ from scipy.ndimage import gaussian_filter
 
 
 
-def run(n_cases=40, seed=0, verbose=True, mode=2):
+def run(n_cases=40, seed=0, verbose=True, mode=2, sweep=0, verify_smooth=False):
     """-> (number of failing cases, worst mean EPE relative to max(1, |flow|max)); mode 2 = fp64 solver storage,
     3 = packed 42-bit storage, None = the library's automatic choice, "verify" = the verification mode against the
-    oracle's `ppow` build, where the bound is BIT-IDENTITY of the float64 flow (a_smooth is forced to 1)"""
+    oracle's `ppow` build, where the bound is BIT-IDENTITY of the float64 flow (a_smooth is forced to 1 unless
+    ``verify_smooth``: the psi_smooth branch runs one iteration per launch chain there, slower); ``sweep`` =
+    fr3d_params.solver_sweep (2 = the window kernel for the a_smooth == 1 sweep of one and two channels)"""
     verify = mode == "verify"
     tol = 0.0 if verify else (1e-4 if mode == 2 else 2e-4)
     if verify:
@@ -42,7 +44,7 @@ def run(n_cases=40, seed=0, verbose=True, mode=2):
                   iterations=int(rng.integers(0, 25)), min_level=int(rng.integers(0, 4)), levels=int(rng.integers(1, 12)),
                   eta=float(rng.choice([0.5, 0.75, 0.8, 0.9])), a_smooth=float(rng.choice([1.0, 1.0, 0.5])),
                   a_data=float(rng.choice([0.45, 1.0, 0.3])))
-        if verify:
+        if verify and not verify_smooth:
             kw["a_smooth"] = 1.0
         if C > 1 and rng.random() < 0.5:
             kw["weight"] = rng.uniform(0.2, 1.0, C)
@@ -58,7 +60,7 @@ def run(n_cases=40, seed=0, verbose=True, mode=2):
                     if verify:
                         fr.get_displacement_verify(fixed, moving, uvw=None if uvw is None else uvw.copy(), **kw)
                     else:
-                        fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, **kw)
+                        fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, solver_sweep=sweep, **kw)
                     bad += 1
                     say("BAD case %2d shape %s: oracle rejects, GPU path accepted" % (case, shape), flush=True)
                 except (ValueError, RuntimeError):
@@ -67,7 +69,7 @@ def run(n_cases=40, seed=0, verbose=True, mode=2):
             if verify:
                 got = fr.get_displacement_verify(fixed, moving, uvw=None if uvw is None else uvw.copy(), **kw)
             else:
-                got = fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, **kw)
+                got = fr.get_displacement(fixed, moving, uvw=None if uvw is None else uvw.copy(), solver_fp64=mode, solver_sweep=sweep, **kw)
             d = np.linalg.norm(got - want, axis=-1)
             scale = max(1.0, float(np.abs(want).max()))
             ok = np.isfinite(got).all() and (np.array_equal(got, want) if verify else d.mean() < tol * scale)
