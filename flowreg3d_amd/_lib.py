@@ -75,7 +75,7 @@ SIGNATURES = {
     "fr3d_motion_tensor_f64": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _vp]),
     "fr3d_level_solve_verify": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,
                                           C.c_double, C.c_double, C.c_double, _vp]),
-    "fr3d_level_solve_tensor": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,
+    "fr3d_level_solve_tensor": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp,
                                           C.c_double, C.c_double, C.c_double, C.c_double, _vp]),
     "fr3d_warp": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "fr3d_warp_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

@@ -301,8 +301,9 @@ def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v,
     downstream, core/optical_flow_3d.py:517-535).
 
     The rank-3 gradient-constancy tensor of get_motion_tensor_gc takes the production solver (square-root factors,
-    fr3d_level_solve).  ANY OTHER tensor -- the reference accepts whatever its caller built -- is solved on its
-    entries by fr3d_level_solve_tensor: the reference's own arithmetic in fp64 (the verification mode's sweep; slower)."""
+    fr3d_level_solve).  ANY OTHER tensor -- the reference accepts whatever its caller built -- and u, v, w whose ghost
+    ring is not the edge pad of the interior are solved on the entries by fr3d_level_solve_tensor: the reference's own
+    arithmetic in fp64 (the verification mode's sweep; slower)."""
     Js = [np.asarray(j) for j in (J11, J22, J33, J44, J12, J13, J23, J14, J24, J34)]
     if Js[0].ndim == 3:
         Js = [j[..., None] for j in Js]
@@ -311,14 +312,14 @@ def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v,
     if wt.ndim == 3:
         wt = wt[..., None]
     inner = (slice(1, -1),) * 3
+    edge_padded = True
     for name, a in (("u", u), ("v", v), ("w", w)):
         a = np.asarray(a)
         if a.shape != (P, M, N):
             raise ValueError(f"{name} must have shape {(P, M, N)}")
-        if not np.array_equal(a, np.pad(a[inner], 1, mode="edge")):
-            # every device kernel takes the ghost ring of u as the edge pad of its interior (add_boundary, :88); a
-            # caller-chosen ring would enter the surface voxels' stencil and psi_smooth
-            raise NotImplementedError("u, v, w must be edge-padded (add_boundary) as in get_displacement")
+        # the production kernels take the ghost ring of u as the edge pad of its interior (add_boundary, :88); a
+        # caller-chosen ring enters the surface voxels' stencil and psi_smooth: solved on the entries path below
+        edge_padded = edge_padded and np.array_equal(a, np.pad(a[inner], 1, mode="edge"))
     Ji = [np.moveaxis(j[inner], -1, 0) for j in Js]  # each (C,Z,Y,X)
     wd = _f32c(np.moveaxis(wt[inner], -1, 0))
     al = (C.c_double * 3)(*[float(x) for x in alpha])
@@ -326,12 +327,16 @@ def level_solver(J11, J22, J33, J44, J12, J13, J23, J14, J24, J34, weight, u, v,
     ad = (C.c_double * nc)(*[float(x) for x in ad_np])
     lib = _lib.init()
     try:
+        if not edge_padded:
+            raise TensorRankError("ghost ring of u, v, w is not the edge pad")
         Ad = _f32c(tensor_factors(*Ji))  # (12,C,Z,Y,X)
     except TensorRankError:
         Jin = np.ascontiguousarray(np.stack([np.stack([Ji[q][c] for q in range(10)]) for c in range(nc)]), np.float64)
         uvw64 = np.ascontiguousarray(np.stack([np.asarray(a)[inner] for a in (u, v, w)], 0), np.float64)
+        ring = None if edge_padded else np.ascontiguousarray(np.stack([np.asarray(a) for a in (u, v, w)], 0), np.float64)
         out64 = np.empty((3, P - 2, M - 2, N - 2), np.float64)
-        _lib.check(lib.fr3d_level_solve_tensor(_lib.ptr(Jin), _lib.ptr(wd), _lib.ptr(uvw64), P - 2, M - 2, N - 2, nc, al,
+        _lib.check(lib.fr3d_level_solve_tensor(_lib.ptr(Jin), _lib.ptr(wd), _lib.ptr(uvw64),
+                                               None if ring is None else _lib.ptr(ring), P - 2, M - 2, N - 2, nc, al,
                                                int(iterations), int(update_lag), ad, float(a_smooth), float(hx), float(hy),
                                                float(hz), _lib.ptr(out64)))
         return tuple(np.pad(out64[d], 1, mode="edge") for d in range(3))

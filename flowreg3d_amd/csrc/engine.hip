@@ -1847,7 +1847,8 @@ int fr3d_motion_tensor_f64(const float *f1, const float *f2, int Z, int Y, int X
 // a_smooth == 1 or not; uvw fp32 or fp64
 static void level_solve_entries(const double *J, const float *weight, const void *uvw, bool uvw_f64, int Z, int Y, int X,
                                 int C, const double *alpha3, int iterations, int update_lag, const double *a_data,
-                                double a_smooth, double hx, double hy, double hz, double *duvw_out)
+                                double a_smooth, double hx, double hy, double hz, double *duvw_out,
+                                const double *uvw_padded = nullptr)
 {
     ensure_init();
     FR3D_CHECK(J && weight && uvw && alpha3 && a_data && duvw_out, "NULL pointer");
@@ -1885,6 +1886,7 @@ static void level_solve_entries(const double *J, const float *weight, const void
     FR3D_HIP(hipMemsetAsync(Drec, 0, ns * 3 * 8, e.st));
     a.U = Urec;
     a.D = Drec;
+    a.Ug = (const double *)s.up(uvw_padded, (size_t)(Z + 2) * (Y + 2) * (X + 2) * 3 * 8);  // nullptr stays nullptr
     a.ax = alpha3[0] / (hx * hx);
     a.ay = alpha3[1] / (hy * hy);
     a.az = alpha3[2] / (hz * hz);
@@ -1899,7 +1901,7 @@ static void level_solve_entries(const double *J, const float *weight, const void
         a.Ps = Ps;
         const SorChainSched &one = e.chain_sched(sk, 1);
         for (int it = 0; it < iterations; it++) {
-            launch_psi_smooth_verify(e.st, sk, Urec, Drec, Dm2, a_smooth, hx, hy, hz, Ps);
+            launch_psi_smooth_verify(e.st, sk, Urec, Drec, Dm2, a_smooth, hx, hy, hz, Ps, a.Ug);
             FR3D_HIP(hipMemcpyAsync(Dm2, Drec, ns * 3 * 8, hipMemcpyDeviceToDevice, e.st));
             a.t_base = it;
             launch_sor_verify(e.st, a, one);
@@ -1919,12 +1921,13 @@ int fr3d_level_solve_verify(const double *J, const float *weight, const float *u
     FR3D_CATCH
 }
 
-int fr3d_level_solve_tensor(const double *J, const float *weight, const double *uvw, int Z, int Y, int X, int C,
-                            const double *alpha3, int iterations, int update_lag, const double *a_data, double a_smooth,
-                            double hx, double hy, double hz, double *duvw_out)
+int fr3d_level_solve_tensor(const double *J, const float *weight, const double *uvw, const double *uvw_padded, int Z, int Y,
+                            int X, int C, const double *alpha3, int iterations, int update_lag, const double *a_data,
+                            double a_smooth, double hx, double hy, double hz, double *duvw_out)
 {
     FR3D_TRY
-    level_solve_entries(J, weight, uvw, true, Z, Y, X, C, alpha3, iterations, update_lag, a_data, a_smooth, hx, hy, hz, duvw_out);
+    level_solve_entries(J, weight, uvw, true, Z, Y, X, C, alpha3, iterations, update_lag, a_data, a_smooth, hx, hy, hz, duvw_out,
+                        uvw_padded);
     FR3D_CATCH
 }
 

@@ -215,13 +215,16 @@ struct VerifyArgs {
     // iteration t is a function of the whole field of t-1), `t_base` = the iteration the launches belong to.
     const double *Ps;
     int t_base;
+    // a caller-chosen ghost ring of u,v,w (level_solver called directly with arrays that are not edge-padded): the
+    // PADDED natural arrays (3, Z+2, Y+2, X+2); nullptr: the ghost ring is the edge pad of the interior (add_boundary)
+    const double *Ug;
 };
 struct SorChainSched;
 long long launch_sor_verify(hipStream_t st, const VerifyArgs &a, const SorChainSched &sc);
 // psi_smooth of one iteration in the reference's arithmetic: D = increments as they stand (iteration t-1), Dm2 = those
 // of iteration t-2 (the padded arrays' ghost ring, set_boundary_3d of the previous iteration), all records of 3 on `sk`
 void launch_psi_smooth_verify(hipStream_t st, const Skew &sk, const double *U, const double *D, const double *Dm2, double a_smooth,
-                              double hx, double hy, double hz, double *Ps);
+                              double hx, double hy, double hz, double *Ps, const double *Ug = nullptr);
 void launch_median5_f64(hipStream_t st, const double *in, int Z, int Y, int X, double *out);
 template <typename TS, typename TD>
 void launch_cast(hipStream_t st, const TS *src, long long n, TD *dst);

@@ -60,9 +60,25 @@ k_sor_verify(const VerifyArgs a, int tau, int t_lo, int nent, const SorEntry *__
     const long long kp = k < Z - 1 ? bzp + jj : c0;
 
     const Rec<double, 3> U0 = ldrec<double, 3>(a.U, c0), D0 = ldrec<double, 3>(a.D, c0);
-    const Rec<double, 3> Uim = ldrec<double, 3>(a.U, im), Uip = ldrec<double, 3>(a.U, ip);
-    const Rec<double, 3> Ujm = ldrec<double, 3>(a.U, jm), Ujp = ldrec<double, 3>(a.U, jp);
-    const Rec<double, 3> Ukm = ldrec<double, 3>(a.U, km), Ukp = ldrec<double, 3>(a.U, kp);
+    Rec<double, 3> Uim = ldrec<double, 3>(a.U, im), Uip = ldrec<double, 3>(a.U, ip);
+    Rec<double, 3> Ujm = ldrec<double, 3>(a.U, jm), Ujp = ldrec<double, 3>(a.U, jp);
+    Rec<double, 3> Ukm = ldrec<double, 3>(a.U, km), Ukp = ldrec<double, 3>(a.U, kp);
+    if (a.Ug) {
+        // a ghost ring that is not the edge pad: u of a missing neighbour comes from the caller's padded arrays
+        const long long gn = X + 2, gm = (long long)(Y + 2) * gn, gp = (long long)(Z + 2) * gm;
+        auto ghost_u = [&](int kk, int jj, int ii) {  // padded coordinates
+            Rec<double, 3> r;
+            const long long o = (long long)kk * gm + (long long)jj * gn + ii;
+            for (int c = 0; c < 3; c++) r.v[c] = a.Ug[(long long)c * gp + o];
+            return r;
+        };
+        if (i == 0) Uim = ghost_u(k + 1, j + 1, 0);
+        if (i == X - 1) Uip = ghost_u(k + 1, j + 1, X + 1);
+        if (j == 0) Ujm = ghost_u(k + 1, 0, i + 1);
+        if (j == Y - 1) Ujp = ghost_u(k + 1, Y + 1, i + 1);
+        if (k == 0) Ukm = ghost_u(0, j + 1, i + 1);
+        if (k == Z - 1) Ukp = ghost_u(Z + 1, j + 1, i + 1);
+    }
     const Rec<double, 3> Dim = ldrec<double, 3>(a.D, im), Dip = ldrec<double, 3>(a.D, ip);
     const Rec<double, 3> Djm = ldrec<double, 3>(a.D, jm), Djp = ldrec<double, 3>(a.D, jp);
     const Rec<double, 3> Dkm = ldrec<double, 3>(a.D, km), Dkp = ldrec<double, 3>(a.D, kp);
@@ -185,7 +201,7 @@ long long launch_sor_verify(hipStream_t st, const VerifyArgs &a, const SorChainS
 // clamped to the padded array, always divided by 2h, the nine squares summed in the reference's order, portable pow.
 __global__ void __launch_bounds__(256)
 k_psi_smooth_verify(const Skew sk, const double *__restrict__ U, const double *__restrict__ D, const double *__restrict__ Dm2,
-                    double a_smooth, double hx, double hy, double hz, double *__restrict__ Ps)
+                    double a_smooth, double hx, double hy, double hz, double *__restrict__ Ps, const double *__restrict__ Ug)
 {
     const int Z = sk.Z, Y = sk.Y, X = sk.X;
     const int P = Z + 2, M = Y + 2, N = X + 2;
@@ -199,7 +215,10 @@ k_psi_smooth_verify(const Skew sk, const double *__restrict__ U, const double *_
         const int jc = jj - 1 < 0 ? 0 : (jj - 1 > Y - 1 ? Y - 1 : jj - 1);
         const int ic = ii - 1 < 0 ? 0 : (ii - 1 > X - 1 ? X - 1 : ii - 1);
         const long long r = sk_index(sk, kc, jc, ic);
-        const Rec<double, 3> u = ldrec<double, 3>(U, r), d = ldrec<double, 3>(ghost ? Dm2 : D, r);
+        Rec<double, 3> u = ldrec<double, 3>(U, r);
+        const Rec<double, 3> d = ldrec<double, 3>(ghost ? Dm2 : D, r);
+        if (ghost && Ug)  // a caller-chosen ghost ring of u,v,w (padded natural arrays, component-major)
+            for (int c = 0; c < 3; c++) u.v[c] = Ug[((long long)c * P + kk) * M * N + (long long)jj * N + ii];
         for (int c = 0; c < 3; c++) o[c] = u.v[c] + d.v[c];
     };
     const int ixm = i > 0 ? i - 1 : 0, ixp = i < N - 1 ? i + 1 : N - 1;
@@ -225,10 +244,10 @@ k_psi_smooth_verify(const Skew sk, const double *__restrict__ U, const double *_
 }
 
 void launch_psi_smooth_verify(hipStream_t st, const Skew &sk, const double *U, const double *D, const double *Dm2, double a_smooth,
-                              double hx, double hy, double hz, double *Ps)
+                              double hx, double hy, double hz, double *Ps, const double *Ug)
 {
     const long long n = (long long)(sk.Z + 2) * (sk.Y + 2) * (sk.X + 2);
-    hipLaunchKernelGGL(k_psi_smooth_verify, dim3(cdiv(n, 256)), dim3(256), 0, st, sk, U, D, Dm2, a_smooth, hx, hy, hz, Ps);
+    hipLaunchKernelGGL(k_psi_smooth_verify, dim3(cdiv(n, 256)), dim3(256), 0, st, sk, U, D, Dm2, a_smooth, hx, hy, hz, Ps, Ug);
     FR3D_LAUNCH_CHECK();
 }
 

@@ -156,11 +156,14 @@ int fr3d_level_solve_verify(const double *J, const float *weight, const float *u
  * re-evaluated every iteration when a_smooth != 1 (core/level_solver_3d.py:262-311,340-546) -- where
  * fr3d_level_solve needs the rank-3 square-root factors of the gradient-constancy tensor.  Slower (no frozen system,
  * one sweep per launch chain when a_smooth != 1); the Python mirror's level_solver takes it for tensors that are
- * not rank 3.  J: (C,10,Z,Y,X) float64, order J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 (interior); weight (C,Z,Y,X)
- * fp32; uvw (3,Z,Y,X) float64 interior flow (ghosts = edge pad); duvw_out (3,Z,Y,X) float64. */
-int fr3d_level_solve_tensor(const double *J, const float *weight, const double *uvw, int Z, int Y, int X, int C,
-                            const double *alpha3, int iterations, int update_lag, const double *a_data,
-                            double a_smooth, double hx, double hy, double hz, double *duvw_out);
+ * not rank 3, and for u, v, w whose ghost ring is not the edge pad of the interior.  J: (C,10,Z,Y,X) float64, order
+ * J11,J22,J33,J44,J12,J13,J23,J14,J24,J34 (interior); weight (C,Z,Y,X) fp32; uvw (3,Z,Y,X) float64 interior flow;
+ * uvw_padded: NULL (ghosts = edge pad of the interior, what get_displacement passes) or the caller's padded arrays
+ * (3,Z+2,Y+2,X+2) float64, whose ring then enters the surface voxels' stencil and psi_smooth exactly as in the
+ * reference; duvw_out (3,Z,Y,X) float64. */
+int fr3d_level_solve_tensor(const double *J, const float *weight, const double *uvw, const double *uvw_padded, int Z,
+                            int Y, int X, int C, const double *alpha3, int iterations, int update_lag,
+                            const double *a_data, double a_smooth, double hx, double hy, double hz, double *duvw_out);
 
 /* Test hook: the verification mode's portable pow (flowreg3d_amd/csrc/portable_pow.h) evaluated on the device for n
  * host values -- tests compare it bit for bit with the same source compiled for the host. */

@@ -336,16 +336,35 @@ def test_level_solver_takes_any_tensor_like_the_reference(hip, oracle, channels,
     uvw = [np.pad(0.7 * gt[..., d] + 0.01 * rng.standard_normal(shape), 1, mode="edge") for d in range(3)]  # float64
     a_data = [0.45, 0.6][:channels]
     alpha = (0.3, 0.25, 0.2)
-    got = hip.level_solver(*J, wt, *uvw, alpha, 11, lag, False, a_data, a_smooth, 1.0, 1.2, 0.9)
-    try:
-        oracle.use_build("ppow")
-        want = oracle.compute_flow_3d(*J, wt, *uvw, *alpha, 11, lag, a_data, a_smooth, 1.0, 1.2, 0.9)
-    finally:
-        oracle.use_build("")
     inner = (slice(1, -1),) * 3
-    for d in range(3):
-        assert got[d].dtype == np.float64 and got[d].shape == (P, M, N)
-        assert np.array_equal(got[d][inner], want[inner + (d,)]), (d, np.abs(got[d][inner] - want[inner + (d,)]).max())
+
+    def check(J_, uvw_):
+        got = hip.level_solver(*J_, wt, *uvw_, alpha, 11, lag, False, a_data, a_smooth, 1.0, 1.2, 0.9)
+        try:
+            oracle.use_build("ppow")
+            want = oracle.compute_flow_3d(*J_, wt, *uvw_, *alpha, 11, lag, a_data, a_smooth, 1.0, 1.2, 0.9)
+        finally:
+            oracle.use_build("")
+        for d in range(3):
+            assert got[d].dtype == np.float64 and got[d].shape == (P, M, N)
+            assert np.array_equal(got[d][inner], want[inner + (d,)]), (d, np.abs(got[d][inner] - want[inner + (d,)]).max())
+        return got
+
+    check(J, uvw)
+    # ... and a ghost ring of u, v, w that is NOT the edge pad of the interior (the reference reads whatever is there:
+    # it enters the surface voxels' stencil and, with a_smooth != 1, psi_smooth): same path, same bits -- with the rank-4
+    # tensor and with the plain gradient-constancy tensor
+    ring = [a.copy() for a in uvw]
+    for a in ring:
+        noise = 0.2 * rng.standard_normal(a.shape)
+        mask = np.ones(a.shape, bool)
+        mask[inner] = False
+        a[mask] += noise[mask]
+    g_ring = check(J, ring)
+    g_edge = hip.level_solver(*J, wt, *uvw, alpha, 11, lag, False, a_data, a_smooth, 1.0, 1.2, 0.9)
+    assert not np.array_equal(g_ring[0][inner], g_edge[0][inner]), "the ghost ring must matter"
+    Jgc = [np.stack([Js[c][q] for c in range(channels)], -1) for q in range(10)]
+    check(Jgc, ring)
 
 
 def test_workgroups_with_equal_id_mod_8_share_an_xcd(hip):
