@@ -270,3 +270,26 @@ np.save(sys.argv[1], np.stack([f1, f2]))
     assert np.array_equal(outs["free"][0], outs["free"][1])          # one lane == two lanes
     assert np.array_equal(outs["tight"][0], outs["free"][0])
     assert np.array_equal(outs["tight"][1], outs["free"][0])
+
+
+def test_small_volumes_run_in_large_lockstep_batches_with_the_single_call_results(hip):
+    """Round 4: the default lock-step batch holds the same number of VOXELS for small volumes as 8 volumes of 256^3 (up
+    to 128 volumes; engine.hip: batch_wanted).  41 small volumes in one call -- two lanes of 20 / 21, far above the old
+    8 -- must give the flows of 41 single get_displacement calls bit for bit (blockIdx.y = volume of the batch)."""
+    from flowreg3d_amd.executor import HipExecutor3D
+    from flowreg3d_amd.synthetic import make_pair
+    shape = (10, 14, 18)
+    fixed, _, _ = make_pair(shape, seed=3)
+    T = 41
+    batch = np.stack([make_pair(shape, seed=3, scale=0.02 * (t + 1))[1] for t in range(T)])[..., None].astype(np.float32)
+    ref = fixed[..., None].astype(np.float32)
+    fp = dict(alpha=(0.25, 0.25, 0.25), update_lag=5, iterations=12, min_level=0, levels=3, eta=0.8, a_smooth=1.0,
+              a_data=0.45)
+    calls = []
+    _, flows = HipExecutor3D().process_batch(batch, batch.astype(np.float64), ref, ref.astype(np.float64),
+                                             np.zeros(shape + (3,), np.float32), None, None,
+                                             progress_callback=lambda k: calls.append(int(k)), flow_params=fp)
+    assert flows.shape == (T,) + shape + (3,) and sum(calls) == T
+    for t in (0, 7, 8, 20, 21, 40):
+        one = hip.get_displacement(ref, batch[t], **fp)
+        assert np.array_equal(flows[t], one.astype(np.float32)), t
