@@ -285,10 +285,10 @@ struct Engine {
             it = scheds.emplace(key, build_sor_schedule(sk, iterations, 4, lag)).first;
         return it->second;
     }
-    const SorChainSched &chain_sched(const Skew &sk, int iterations)
+    // by, nch <= 0: the plane sweep's own tile shape
+    const SorChainSched &chain_sched(const Skew &sk, int iterations, int by = 0, int nch = 0)
     {
-        int by, nch;
-        sor_tile_shape(sk, by, nch);
+        if (by <= 0 || nch <= 0) sor_tile_shape(sk, by, nch);
         auto key = std::make_tuple(sk.Z, sk.Y, sk.X, iterations, by, nch);
         auto it = chain_scheds.find(key);
         if (it == chain_scheds.end()) {
@@ -688,7 +688,18 @@ static void get_displacement_core_t(Engine &e, const fr3d_params &p, const std::
                 }
             }
             FR3D_HIP(hipMemsetAsync(smD, 0, ns * 9 * nb * sizeof(S), e.st));
-            long long n = launch_sor_smooth<S>(e.st, sa, e.sched(sk, p.iterations, SM_LAG));
+            long long n;
+#ifdef FR3D_EXPERIMENTS
+            // FR3D_SMOOTH=fused|paired: P-stage and sweep tiles sharing the plane between them (k_sor_smooth.hip; -12 % HBM
+            // traffic, 7 % slower: profiles/r04/smooth_fusion.md)
+            static const char *sm_env = getenv("FR3D_SMOOTH");
+            const bool fused = sm_env && (!strcmp(sm_env, "fused") || !strcmp(sm_env, "paired")) && 2 * p.iterations <= 32767;
+            if (fused)
+                n = launch_sor_smooth_fused<S>(e.st, sa, e.sched(sk, p.iterations, SM_LAG), e.chain_sched(sk, 2 * p.iterations, 4, 2),
+                                               !strcmp(sm_env, "paired"));
+            else
+#endif
+            n = launch_sor_smooth<S>(e.st, sa, e.sched(sk, p.iterations, SM_LAG));
             if (p.iterations > 0) {
                 for (int b = 0; b < nb; b++)
                     FR3D_HIP(hipMemcpyAsync(dbuf + (size_t)b * a.vsD, sa.D[(p.iterations - 1) % 3] + (size_t)b * sa.vsD,

@@ -269,8 +269,13 @@ inline void smooth_set_spacing(SmoothView<S> &v, double hx, double hy, double hz
 }
 
 struct SorSched;
+struct SorChainSched;
 template <typename S>
 long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSched &sched);
+// experiment build: P-stage and sweep tiles sharing the plane between them (chain schedule of 2 x iterations, shape 4 x 2)
+template <typename S>
+long long launch_sor_smooth_fused(hipStream_t st, const SmoothArgs<S> &a, const SorSched &sched, const SorChainSched &chain,
+                                  bool paired);
 
 // ---- launchers (each enqueues on `st`, no synchronisation) ------------------------------------
 

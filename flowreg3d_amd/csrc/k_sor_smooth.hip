@@ -430,4 +430,128 @@ long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSch
 template long long launch_sor_smooth<float>(hipStream_t, const SmoothArgs<float> &, const SorSched &);
 template long long launch_sor_smooth<double>(hipStream_t, const SmoothArgs<double> &, const SorSched &);
 
+#ifdef FR3D_EXPERIMENTS
+// ---- fused form (round 4): P-stage and sweep tiles in ONE 512-thread workgroup ---------------------------------------
+// With v = 2t for the P-stage of iteration t and v = 2t + 1 for its sweep, "virtual iteration" v works on hyperplane
+// tau - 2v in launch tau -- the plane sweep's own pipeline with 2T iterations -- and the chain schedule of k_sor.hip
+// (build_sor_chain_schedule, rows x chain positions = 4 x 2) pairs two consecutive v in one workgroup: position n takes
+// rows k - n of plane s0 - 2n, so both positions read the SAME rows of the odd plane between them (the P-stage of plane q
+// and the sweep of plane q - 2 share the rows of plane q - 1; a pair that starts at an odd v shares plane q - 3 between
+// the sweep of t and the P-stage of t + 1).  The second reader finds them in the CU's L1 / the XCD's L2.  Dependences are
+// those of the split form (psi_s^t two planes ahead of sweep t, sweep t two planes ahead of psi_s^{t+1}); the surface
+// voxels keep their dense workgroups (512 lanes here).  Same per-voxel functions: bit-identical results.
+// Measured (profiles/r04/smooth_fusion.md): HBM traffic 342 -> 299.5 B per update, and 7 % SLOWER on one lane (level on
+// two): experiment build only (FR3D_SMOOTH=fused|paired), the split form ships.
+template <typename S>
+__device__ __forceinline__ bool locate_surface512(const SmoothArgs<S> &a, int b, int cb, const StepPart &P,
+                                                  const int *__restrict__ meta, const int *__restrict__ kj, SmoothPos &p)
+{
+    p.t = P.t_lo + b / cb;
+    const int s = P.tau - SM_LAG * p.t;
+    if (s < 0 || s >= a.S_planes) return false;
+    const int n = (b % cb) * 512 + (threadIdx.z * 4 + threadIdx.y) * 64 + threadIdx.x;
+    if (n >= meta[2 * s + 1]) return false;
+    const int v = kj[meta[2 * s] + n];
+    return smooth_offsets(a, s, v >> 16, v & 0xffff, false, p);
+}
+
+// PAIRED: the two chain positions of a tile run as two 256-thread workgroups of their own, 8 workgroup ids apart --
+// workgroups are dealt round-robin over the 8 XCDs, so the pair shares an L2 and is dispatched at about the same time --
+// instead of one 512-thread workgroup (whose P-stage waves finish early and hold their slots until the sweep waves are done)
+template <typename S, int C, bool PAIRED>
+__global__ void __launch_bounds__(PAIRED ? 256 : 512) SM_WPE_ATTR
+k_smooth_fused(const SmoothArgs<S> a, int tau, int v_lo, int nent, const SorEntry *__restrict__ ent,
+               const int *__restrict__ lut, int ntiles, StepPart P, StepPart W, int cb, const int *__restrict__ meta,
+               const int *__restrict__ kj)
+{
+    int b = blockIdx.x;
+    SmoothPos p;
+    const int nwg = PAIRED ? ((ntiles + 7) / 8) * 16 : ntiles;  // workgroup ids of the tiles
+    if (b < nwg) {
+        int n = __builtin_amdgcn_readfirstlane((int)threadIdx.z);
+        if (PAIRED) {
+            n = (b & 15) >> 3;
+            b = (b >> 4) * 8 + (b & 7);
+            if (b >= ntiles) return;
+        }
+        int lo = lut[b >> SOR_LUT_SHIFT];
+        while (lo + 1 < nent && ent[lo + 1].pre <= b) lo++;
+        const SorEntry en = ent[lo];
+        const int local = b - en.pre;
+        if (n >= sor_entry_nit(en)) return;
+        const int v = v_lo + sor_entry_toff(en) + n;
+        const int s = tau - 2 * v;
+        const int k = (en.kb0 + local / en.njb) * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.y) - n;
+        if (k < 0 || s < 0 || s >= a.S_planes) return;
+        const int jj = (local % en.njb) * 64 + threadIdx.x;
+        p.t = v >> 1;
+        if (!smooth_offsets(a, s, k, jj, true, p)) return;
+        if (on_surface(a, p)) return;
+        if (v & 1) sweep_voxel<S, C, true>(a, p);
+        else psi_voxel<S, true>(a, p);
+        return;
+    }
+    b -= nwg;
+    if (b < P.nt * cb) {
+        if (PAIRED ? locate_surface(a, b, cb, P, meta, kj, p) : locate_surface512(a, b, cb, P, meta, kj, p)) psi_voxel<S, false>(a, p);
+        return;
+    }
+    b -= P.nt * cb;
+    if (PAIRED ? locate_surface(a, b, cb, W, meta, kj, p) : locate_surface512(a, b, cb, W, meta, kj, p)) sweep_voxel<S, C, false>(a, p);
+}
+
+template <typename S>
+long long launch_sor_smooth_fused(hipStream_t st, const SmoothArgs<S> &a, const SorSched &sc, const SorChainSched &ch, bool paired)
+{
+    if (a.iterations <= 0) return 0;
+    FR3D_CHECK(sc.lag == SM_LAG && sc.bnd_kj && sc.bnd_meta, "internal: smooth solver needs the lag-4 schedule");
+    FR3D_CHECK(ch.by == 4 && ch.nch == 2, "internal: the fused smooth solver runs 64 x 4 x 2 workgroups");
+    const dim3 block(64, 4, paired ? 1 : 2);
+    const int cb = cdiv(std::max(sc.bnd_max, 1), paired ? 256 : 512);
+    long long launches = 0;
+    const int last = (int)sc.launch_of_tau.size() - 1;
+    auto part = [&](int tau) {
+        StepPart p{0, 0, 0, 0, nullptr, nullptr};
+        if (tau < 0 || tau > last || sc.launch_of_tau[tau] < 0) return p;
+        const int l = sc.launch_of_tau[tau];
+        p.tau = sc.tau[l]; p.t_lo = sc.t_lo[l]; p.nt = sc.nt[l]; p.ntiles = sc.ntiles[l];
+        p.ent = sc.entries + sc.first[l];
+        p.lut = sc.lut + sc.lut_first[l];
+        return p;
+    };
+    for (size_t l = 0; l < ch.tau.size(); l++) {
+        const int tau = ch.tau[l];
+        const StepPart P = part(tau), W = part(tau - 2);
+        const int nwg = paired ? ((ch.ntiles[l] + 7) / 8) * 16 : ch.ntiles[l];
+        const int blocks = nwg + (P.nt + W.nt) * cb;
+        if (blocks <= 0) continue;
+        const dim3 grid(blocks, a.nvol > 0 ? a.nvol : 1);
+#define FR3D_SM_FUSED(CC)                                                                                                   \
+    if (paired)                                                                                                              \
+        hipLaunchKernelGGL((k_smooth_fused<S, CC, true>), grid, block, 0, st, a, tau, ch.t_lo[l], ch.nent[l],                \
+                           ch.entries + ch.first[l], ch.lut + ch.lut_first[l], ch.ntiles[l], P, W, cb, sc.bnd_meta, sc.bnd_kj); \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((k_smooth_fused<S, CC, false>), grid, block, 0, st, a, tau, ch.t_lo[l], ch.nent[l],               \
+                           ch.entries + ch.first[l], ch.lut + ch.lut_first[l], ch.ntiles[l], P, W, cb, sc.bnd_meta, sc.bnd_kj)
+        switch (a.C) {
+            case 1: FR3D_SM_FUSED(1); break;
+            case 2: FR3D_SM_FUSED(2); break;
+            case 3: FR3D_SM_FUSED(3); break;
+            case 4: FR3D_SM_FUSED(4); break;
+            default:
+                FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
+                FR3D_SM_FUSED(0);
+                break;
+        }
+#undef FR3D_SM_FUSED
+        FR3D_LAUNCH_CHECK();
+        launches++;
+    }
+    return launches;
+}
+template long long launch_sor_smooth_fused<float>(hipStream_t, const SmoothArgs<float> &, const SorSched &, const SorChainSched &, bool);
+template long long launch_sor_smooth_fused<double>(hipStream_t, const SmoothArgs<double> &, const SorSched &, const SorChainSched &, bool);
+#endif  // FR3D_EXPERIMENTS
+
+
 }  // namespace fr3d
