@@ -22,6 +22,7 @@
 //    contiguous, compact skewed rows), so a neighbour costs three wide loads instead of seven dword loads, and
 //    the volumes of a lock-step batch share the launches (blockIdx.y = volume of the batch).
 #include <cstdlib>
+#include <cstring>
 
 #include "fr3d_internal.h"
 #include "k_sor_core.h"
@@ -341,7 +342,7 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
     strec<S, 3>(Dn, c0, out);
 }
 
-// One launch per step n, four kinds of workgroups: P-stage tiles (psi_s^t on plane n - 4t, interior
+// One step n, four kinds of workgroups: P-stage tiles (psi_s^t on plane n - 4t, interior
 // voxels), sweep tiles (iteration t on plane n - 2 - 4t, interior voxels), and for each of the two the
 // surface voxels of the same planes packed 256 to a workgroup.  Within a step all four are independent:
 // the sweep reads psi_s of planes finished in earlier steps, the P-stage increments swept in earlier steps.
@@ -352,6 +353,7 @@ __device__ __forceinline__ void sweep_voxel(const SmoothArgs<S> &a, const Smooth
 #define SM_WPE 4
 #endif
 #define SM_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SM_WPE, SM_WPE)))
+#ifdef FR3D_EXPERIMENTS  // both stages in one kernel: the form of rounds 2-3, kept for FR3D_SM_DBG decompositions
 template <typename S, int C>
 __global__ void __launch_bounds__(256) SM_WPE_ATTR
 k_smooth_step(const SmoothArgs<S> a, StepPart P, StepPart W, int cb, const int *__restrict__ meta,
@@ -385,6 +387,38 @@ k_smooth_step(const SmoothArgs<S> a, StepPart P, StepPart W, int cb, const int *
     SM_SKIP(8)
     if (locate_surface(a, b, cb, W, meta, kj, p)) sweep_voxel<S, C, false>(a, p);
 }
+#endif
+
+// The stages as kernels of their own (same stream, round 4): the P-stage needs 64 VGPRs (8 waves per SIMD) where the
+// sweep needs 110-128 (4 waves), and in one kernel both ran at the sweep's occupancy.
+template <typename S>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_smooth_psi_only(const SmoothArgs<S> a, StepPart P, int cb, const int *__restrict__ meta, const int *__restrict__ kj)
+{
+    int b = blockIdx.x;
+    SmoothPos p;
+    if (b < P.ntiles) {
+        if (locate_tile(a, b, P, p)) psi_voxel<S, true>(a, p);
+        return;
+    }
+    b -= P.ntiles;
+    if (locate_surface(a, b, cb, P, meta, kj, p)) psi_voxel<S, false>(a, p);
+}
+// SURFACE: the surface workgroups instead of the tiles (a launch of its own: the tiles then run without the surface form's
+// scratch, and the short launch fills in under the other engine lane -- two lanes 4.22 -> 4.38 volumes/s; the P-stage's
+// tiles and surface workgroups in separate launches measured 268 against 251 ms and stay together)
+// (the tiles at 5 waves per SIMD -- 96 VGPRs, 80 B of scratch -- measured 319 against 250 ms)
+template <typename S, int C, bool SURFACE>
+__global__ void __launch_bounds__(256) SM_WPE_ATTR
+k_smooth_sweep_only(const SmoothArgs<S> a, StepPart W, int cb, const int *__restrict__ meta, const int *__restrict__ kj)
+{
+    SmoothPos p;
+    if (!SURFACE) {
+        if (locate_tile(a, blockIdx.x, W, p)) sweep_voxel<S, C, true>(a, p);
+    } else {
+        if (locate_surface(a, blockIdx.x, cb, W, meta, kj, p)) sweep_voxel<S, C, false>(a, p);
+    }
+}
 
 // One schedule (SM_LAG planes between iterations) serves both stages: step n runs the P-stage with
 // tau = n and the sweep with tau = n - 2, i.e. psi_s^t is two planes ahead of sweep t.
@@ -407,11 +441,45 @@ long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSch
         p.lut = sc.lut + sc.lut_first[l];
         return p;
     };
+    bool two = true;
+#ifdef FR3D_EXPERIMENTS
+    static const char *one_env = getenv("FR3D_SMOOTH");  // "one": both stages in one kernel (the form of rounds 2-3; FR3D_SM_DBG)
+    two = !(one_env && !strcmp(one_env, "one"));
+#endif
+    const int nv = a.nvol > 0 ? a.nvol : 1;
     for (int n = 0; n <= last + 2; n++) {
         const StepPart P = part(n), W = part(n - 2);
         const int blocks = P.ntiles + W.ntiles + (P.nt + W.nt) * cb;
         if (blocks <= 0) continue;
-        const dim3 grid(blocks, a.nvol > 0 ? a.nvol : 1);
+        if (two) {
+            // three launches per step: the P-stage at 8 waves per SIMD, the sweep's tiles and its surface workgroups at 4
+            // (250 against 274 ms per 256^3 volume for one launch per step)
+            const int bp = P.ntiles + P.nt * cb;
+            if (bp > 0) hipLaunchKernelGGL((k_smooth_psi_only<S>), dim3(bp, nv), block, 0, st, a, P, cb, sc.bnd_meta, sc.bnd_kj);
+#define FR3D_SM_SWEEP(CC)                                                                                                       \
+    {                                                                                                                            \
+        if (W.ntiles > 0)                                                                                                        \
+            hipLaunchKernelGGL((k_smooth_sweep_only<S, CC, false>), dim3(W.ntiles, nv), block, 0, st, a, W, cb, sc.bnd_meta, sc.bnd_kj); \
+        if (W.nt * cb > 0)                                                                                                       \
+            hipLaunchKernelGGL((k_smooth_sweep_only<S, CC, true>), dim3(W.nt * cb, nv), block, 0, st, a, W, cb, sc.bnd_meta, sc.bnd_kj); \
+    }
+            switch (a.C) {
+                case 1: FR3D_SM_SWEEP(1); break;
+                case 2: FR3D_SM_SWEEP(2); break;
+                case 3: FR3D_SM_SWEEP(3); break;
+                case 4: FR3D_SM_SWEEP(4); break;
+                default:
+                    FR3D_CHECK(a.C >= 1 && a.C <= FR3D_MAX_CHANNELS, "SOR kernel: channel count out of range");
+                    FR3D_SM_SWEEP(0);
+                    break;
+            }
+#undef FR3D_SM_SWEEP
+            FR3D_LAUNCH_CHECK();
+            launches++;
+            continue;
+        }
+#ifdef FR3D_EXPERIMENTS
+        const dim3 grid(blocks, nv);
         switch (a.C) {
             case 1: hipLaunchKernelGGL((k_smooth_step<S, 1>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
             case 2: hipLaunchKernelGGL((k_smooth_step<S, 2>), grid, block, 0, st, a, P, W, cb, sc.bnd_meta, sc.bnd_kj); break;
@@ -424,6 +492,7 @@ long long launch_sor_smooth(hipStream_t st, const SmoothArgs<S> &a, const SorSch
         }
         FR3D_LAUNCH_CHECK();
         launches++;
+#endif
     }
     return launches;
 }
