@@ -391,6 +391,7 @@ k_smooth_step(const SmoothArgs<S> a, StepPart P, StepPart W, int cb, const int *
 
 // The stages as kernels of their own (same stream, round 4): the P-stage needs 64 VGPRs (8 waves per SIMD) where the
 // sweep needs 110-128 (4 waves), and in one kernel both ran at the sweep's occupancy.
+// (7 waves per SIMD -- 72 VGPRs, what the surface form asks for -- measured the same as 8)
 template <typename S>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_smooth_psi_only(const SmoothArgs<S> a, StepPart P, int cb, const int *__restrict__ meta, const int *__restrict__ kj)
@@ -408,8 +409,10 @@ k_smooth_psi_only(const SmoothArgs<S> a, StepPart P, int cb, const int *__restri
 // scratch, and the short launch fills in under the other engine lane -- two lanes 4.22 -> 4.38 volumes/s; the P-stage's
 // tiles and surface workgroups in separate launches measured 268 against 251 ms and stay together)
 // (the tiles at 5 waves per SIMD -- 96 VGPRs, 80 B of scratch -- measured 319 against 250 ms)
+// The surface workgroups at 3 waves per SIMD: their form asks for 153 VGPRs, and under the tiles' cap of 128 it spilled
+// 132 B per lane (249 -> 238 ms per volume).
 template <typename S, int C, bool SURFACE>
-__global__ void __launch_bounds__(256) SM_WPE_ATTR
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SURFACE ? 3 : SM_WPE, SURFACE ? 3 : SM_WPE)))
 k_smooth_sweep_only(const SmoothArgs<S> a, StepPart W, int cb, const int *__restrict__ meta, const int *__restrict__ kj)
 {
     SmoothPos p;
