@@ -392,7 +392,7 @@ def measure(lib, _lib, workload, K, W, batch_arg, condition, solver_fp64, rank, 
         per_launch = sor["units"] / max(sor["launches"], 1)
         res["roofline"] = {"bound": "hbm",
                            "kernel": "k_sor_step (SOR hyperplane sweep)" if a_smooth == 1.0 else
-                                     "k_smooth_step + k_smooth_psi (psi_smooth SOR sweep, a_smooth != 1)",
+                                     "k_smooth_psi_only + k_smooth_sweep_only (psi_smooth SOR sweep, a_smooth != 1: three launches per step, counted as one)",
                            "algo_bytes_per_update": contract_basis,
                            "basis": f"SURVEY 8d: {vals} values per voxel update ({'9 J + w psi + 3 L + 3 d read, 3 d written' if a_smooth == 1.0 else '9 J + w psi + 3 u + 3 d + psi_s read, 3 d written; psi_s: 3 u + 3 d read, 1 written'}) "
                                     "x 4 B (the fp32 figure of the contract, independent of this mode's storage format)",
