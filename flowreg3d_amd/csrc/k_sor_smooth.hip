@@ -392,8 +392,10 @@ k_smooth_step(const SmoothArgs<S> a, StepPart P, StepPart W, int cb, const int *
 // The stages as kernels of their own (same stream, round 4): the P-stage needs 64 VGPRs (8 waves per SIMD) where the
 // sweep needs 110-128 (4 waves), and in one kernel both ran at the sweep's occupancy.
 // (7 waves per SIMD -- 72 VGPRs, what the surface form asks for -- measured the same as 8)
+// fp64 storage: 4 waves per SIMD (116 VGPRs; at 8 the kernel spills 196 B per lane: 1790 -> 1695 ms on the two-channel
+// 256 x 512 x 512 case)
 template <typename S>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(S) == 8 ? 4 : 8, sizeof(S) == 8 ? 4 : 8)))
 k_smooth_psi_only(const SmoothArgs<S> a, StepPart P, int cb, const int *__restrict__ meta, const int *__restrict__ kj)
 {
     int b = blockIdx.x;
@@ -411,8 +413,12 @@ k_smooth_psi_only(const SmoothArgs<S> a, StepPart P, int cb, const int *__restri
 // (the tiles at 5 waves per SIMD -- 96 VGPRs, 80 B of scratch -- measured 319 against 250 ms)
 // The surface workgroups at 3 waves per SIMD: their form asks for 153 VGPRs, and under the tiles' cap of 128 it spilled
 // 132 B per lane (249 -> 238 ms per volume).
+// the sweep's tiles: 4 waves per SIMD for one channel with 4-byte storage (110 VGPRs), 3 for fp64 storage and for several
+// channels (136-168 VGPRs: under the cap of 128 they spilled up to 228 B per lane; two channels with fp64 storage,
+// 256 x 512 x 512: 2287 -> 1825 ms of solver time per volume, 512^3 one channel: 3920 -> 3234)
+#define SM_TILE_WPE(S, C) ((sizeof(S) == 8 || (C) != 1) ? 3 : SM_WPE)
 template <typename S, int C, bool SURFACE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SURFACE ? 3 : SM_WPE, SURFACE ? 3 : SM_WPE)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SURFACE ? 3 : SM_TILE_WPE(S, C), SURFACE ? 3 : SM_TILE_WPE(S, C))))
 k_smooth_sweep_only(const SmoothArgs<S> a, StepPart W, int cb, const int *__restrict__ meta, const int *__restrict__ kj)
 {
     SmoothPos p;
