@@ -222,6 +222,7 @@ k_sor_step(const SorArgsT<S> a, int tau, int t_lo, int nent, const SorEntry *__r
         using V = typename Sto<S>::val;
         out.v[0] = (V)(float)du1; out.v[1] = (V)(float)dv1; out.v[2] = (V)(float)dw1;
     }
+    if (a.dbg & 128) bfp_round(out.v, 0, 3, (a.dbg >> 8) & 0xff);  // du, dv, dw with one exponent
 #endif
     strec<S, 3>(D, c0, out);
 }

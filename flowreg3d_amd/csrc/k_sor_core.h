@@ -19,6 +19,22 @@ template <typename R> FR3D_HD R fma_(R a, R b, R c);
 template <> FR3D_HD float fma_<float>(float a, float b, float c) { return fmaf(a, b, c); }
 template <> FR3D_HD double fma_<double>(double a, double b, double c) { return fma(a, b, c); }
 
+#ifdef FR3D_EXPERIMENTS
+// numerics what-if (FR3D_SOR_DBG bits 64 / 128, mantissa bits in bits 8..15): round a group of values to a BLOCK
+// floating-point format -- one shared exponent (that of the largest magnitude) and `bits` magnitude bits each
+template <typename V, int N>
+__device__ __forceinline__ void bfp_round(V (&v)[N], int first, int n, int bits)
+{
+    double mx = 0.0;
+    for (int q = 0; q < n; q++) mx = fmax(mx, fabs((double)v[first + q]));
+    if (!(mx > 0.0) || !(mx < 1e300)) return;
+    int ex;
+    (void)frexp(mx, &ex);  // mx < 2^ex
+    const double scale = ldexp(1.0, ex - bits);
+    for (int q = 0; q < n; q++) v[first + q] = (V)(rint((double)v[first + q] / scale) * scale);
+}
+#endif
+
 FR3D_HD double bits_double(unsigned hi, unsigned lo)
 {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
@@ -293,6 +309,10 @@ __device__ __forceinline__ void sor_system(const SorArgsT<S> &a, bool upd, bool 
         if (a.dbg & 2) {
 #pragma unroll
             for (int q = 0; q < 9; q++) mr.v[q] = (V)(float)mr.v[q];
+        }
+        if (a.dbg & 64) {  // M11..M23 with one exponent, b with another
+            bfp_round(mr.v, 0, 6, (a.dbg >> 8) & 0xff);
+            bfp_round(mr.v, 6, 3, (a.dbg >> 8) & 0xff);
         }
 #endif
         if (store) strec<S, 9>(a.M + vM, e, mr);

@@ -26,7 +26,7 @@ def main():
     lib = _lib.init(0)
     g = np.load(os.path.join(ROOT, "tests", "golden", f"fullsize_{case}.npz"))
     meta = json.loads(bytes(g["meta"]).decode())
-    fixed, moving, gt, kw = fullsize_case(case)
+    fixed, moving, gt, kw = fullsize_case(case, warp=fr.imregister_wrapper)
     st, bl = meta["stride"], meta["block"]
     z0, y0, x0 = meta["block_origin_zyx"]
     for m in modes:
